@@ -1,0 +1,237 @@
+/*
+ * include/mifsk.h -- batch C ABI of the MI355X-native FSK demodulator.
+ *
+ * include/fsk.h keeps the reference's five-function API.  One fsk_find_frame()
+ * call covers <= ~10 kB of audio, so offloading it call by call is launch-
+ * and PCIe-bound.  This header is the extension that makes the path worth
+ * running on a GPU: whole streams resident in HBM, and the reference's
+ * receive loop (main() in src/minimodem.c:1137-1463 -- the only caller of
+ * fsk_find_frame) executed on the device, one workgroup per stream.
+ *
+ * Everything here is plain C: PODs, pointers and sizes.  Pointers whose name
+ * starts with d_ are DEVICE pointers (hipMalloc / torch.cuda tensors); all
+ * others are host pointers.  `stream` arguments are a hipStream_t passed as
+ * void* (NULL = the default stream).  Functions return 0 on success or a
+ * negative errno value; nothing aborts across this boundary.
+ *
+ *   entry point                   stands in for (reference file:line)
+ *   mifsk_modem_args_default      option defaults        minimodem.c:492-553
+ *   mifsk_rx_config_init          preset + derived state minimodem.c:819-965,1037-1131
+ *                                 and plan bins          fsk.c:52-57
+ *   mifsk_ctx_create/destroy      fsk_plan_new/destroy   fsk.c:33-104
+ *   mifsk_find_frame_batch        fsk_find_frame         fsk.c:449-538 (N problems)
+ *   mifsk_demod_batch             the --rx main loop     minimodem.c:1137-1463
+ *   mifsk_demod_batch_host        same, host buffers     (H2D + demod + D2H)
+ */
+#ifndef MIFSK_H
+#define MIFSK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIFSK_MAX_FRAME_BITS	64	/* fsk.c:185-187,463 */
+#define MIFSK_ABI_VERSION	1
+
+/* which databits decoder main() would have selected (minimodem.c:549-553,
+ * 675,820,856,866,892).  Decoding frame bits to text is O(1)/frame host work
+ * on the gathered frames; the device emits frame bits. */
+enum mifsk_decoder {
+    MIFSK_DECODE_ASCII8	= 0,
+    MIFSK_DECODE_BAUDOT	= 1,
+    MIFSK_DECODE_BINARY	= 2,
+    MIFSK_DECODE_CALLERID = 3,
+    MIFSK_DECODE_UIC_GROUND = 4,
+    MIFSK_DECODE_UIC_TRAIN = 5
+};
+
+/* The --rx command line, as data.  Zero / negative means "not given". */
+typedef struct mifsk_modem_args {
+    const char	*baudmode;	/* "1200" "300" "rtty" "tdd" "same" "callerid"
+				   "uic-train" "uic-ground" "V.21" or a number */
+    unsigned	sample_rate;	/* -R            (0 -> 48000)              */
+    float	mark_f;		/* -M            (0 -> mode default)       */
+    float	space_f;	/* -S            (0 -> mode default)       */
+    float	band_width;	/* -b            (0 -> mode default)       */
+    int		n_data_bits;	/* -8 / -7 / -5  (0 -> mode default)       */
+    int		baudot;		/* -5 also selects the baudot decoder      */
+    int		nstartbits;	/* --startbits   (<0 -> 1)                 */
+    float	nstopbits;	/* --stopbits    (<0 -> 1.0)               */
+    int		invert_start_stop;	/* --invert-start-stop             */
+    int		inverted_freqs;	/* -i                                      */
+    int		msb_first;	/* --msb-first                             */
+    int		have_sync_byte;	/* --sync-byte given                       */
+    long long	sync_byte;
+    float	confidence_threshold;	/* -c (<0 -> 1.5)                  */
+    float	search_limit;	/* -l            (<0 -> 2.3)               */
+    int		binary_output;	/* --binary-output                         */
+    int		binary_raw_nbits;	/* --binary-raw N                  */
+    int		rx_one;		/* --rx-one                                */
+    float	auto_carrier_threshold;	/* -a -> 0.001; not supported by the
+					   batch path yet (-ENOSYS)        */
+} mifsk_modem_args;
+
+/* Everything main() derives before entering the receive loop, computed on the
+ * host in C `float` with the reference's own expressions and truncations. */
+typedef struct mifsk_rx_config {
+    /* modem */
+    unsigned	sample_rate;
+    float	data_rate;
+    float	mark_f, space_f, band_width;
+    unsigned	n_data_bits;
+    int		nstartbits;
+    float	nstopbits;
+    int		invert_start_stop;
+    int		msb_first;
+    int		do_rx_sync;
+    unsigned long long sync_byte;
+    int		decoder;		/* enum mifsk_decoder */
+    int		rx_one;
+    float	confidence_threshold;
+    float	search_limit;
+    float	auto_carrier_threshold;
+    int		autodetect_shift;
+    int		inverted_freqs;
+
+    /* plan (fsk.c:52-57) */
+    int		fftsize;
+    unsigned	nbands;
+    unsigned	b_mark, b_space;
+
+    /* framing (minimodem.c:943,1037,1105-1131) */
+    unsigned	frame_n_bits;		/* unsigned = n_data + nstart + nstop(float) */
+    float	nsamples_per_bit;
+    unsigned	nsamples_overscan;
+    unsigned	frame_nsamples;
+    unsigned	expect_n_bits;
+    unsigned	expect_nsamples;
+    char	expect_data[MIFSK_MAX_FRAME_BITS + 4];
+    char	expect_sync[MIFSK_MAX_FRAME_BITS + 4];
+    unsigned	samplebuf_size;		/* minimodem.c:1063-1070 */
+
+    /* search grid; index 0 = no carrier, 1 = carrier (minimodem.c:1236-1263,1366) */
+    unsigned	try_first[2];
+    unsigned	try_max[2];
+    unsigned	try_step[2];
+    unsigned	try_step_fine[2];
+
+    /* bit windows inside fsk_find_frame (fsk.c:183,204,465) */
+    float	find_samples_per_bit;	/* (float)expect_nsamples / expect_n_bits */
+    unsigned	bit_nsamples;
+    unsigned	bit_offset[MIFSK_MAX_FRAME_BITS];
+} mifsk_rx_config;
+
+void mifsk_modem_args_default( mifsk_modem_args *args );
+int  mifsk_rx_config_init( mifsk_rx_config *cfg, const mifsk_modem_args *args );
+
+/* upper bound on frames one stream of nsamples can yield */
+size_t mifsk_max_frames( const mifsk_rx_config *cfg, size_t nsamples );
+/* zero-filled floats the caller must keep readable after each stream's last
+ * sample (reads past the end of a stream see zeros; the reference reads stale
+ * ring-buffer memory there -- DESIGN.md "past-the-end reads") */
+size_t mifsk_stream_padding( const mifsk_rx_config *cfg );
+
+/* ---- device context --------------------------------------------------- */
+
+typedef struct mifsk_ctx mifsk_ctx;
+
+/* device < 0: use the current HIP device.  -ENODEV when none is usable. */
+int  mifsk_ctx_create( mifsk_ctx **ctx_out, int device );
+void mifsk_ctx_destroy( mifsk_ctx *ctx );
+const char *mifsk_ctx_device_name( const mifsk_ctx *ctx );
+int  mifsk_abi_version( void );
+
+/* ---- N independent fsk_find_frame() problems --------------------------- */
+
+typedef struct mifsk_search {
+    uint64_t	sample_offset;	/* window start, in floats, into d_samples  */
+    uint32_t	navail;		/* readable floats from there; beyond = 0.0 */
+    uint32_t	try_first;
+    uint32_t	try_max;
+    uint32_t	try_step;
+    float	search_limit;
+    uint32_t	use_sync_string;	/* 0: cfg->expect_data, 1: cfg->expect_sync */
+} mifsk_search;
+
+typedef struct mifsk_search_result {
+    uint64_t	bits;
+    float	confidence;
+    float	amplitude;
+    uint32_t	frame_start;
+    uint32_t	n_positions;	/* positions the reference would have analysed */
+} mifsk_search_result;
+
+int mifsk_find_frame_batch( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
+	const float *d_samples,
+	const mifsk_search *d_problems, mifsk_search_result *d_results,
+	int nproblems, void *stream );
+
+/* ---- whole-stream receive loop ----------------------------------------- */
+
+/* one decoded frame, in loop order (optional detailed output) */
+typedef struct mifsk_frame {
+    uint64_t	bits;		/* data bits handed to the databits decoder
+				   (after >>1, bit_window, bit_reverse)     */
+    uint64_t	start;		/* absolute sample index of the frame start */
+    float	confidence;
+    float	amplitude;
+    uint32_t	flags;		/* MIFSK_FRAME_* */
+    uint32_t	reserved;
+} mifsk_frame;
+
+#define MIFSK_FRAME_ACQUIRE	1u	/* carrier was acquired on this frame   */
+#define MIFSK_FRAME_SYNC	2u	/* == sync byte: suppressed from output */
+#define MIFSK_FRAME_REFINED	4u	/* a fine rescan was run for this frame */
+
+/* one carrier episode = what "### CARRIER" ... "### NOCARRIER" brackets */
+typedef struct mifsk_episode {
+    uint64_t	carrier_nsamples;
+    uint32_t	first_frame;	/* index of its first frame in loop order   */
+    uint32_t	nframes;	/* nframes_decoded                          */
+    float	confidence_total;
+    float	amplitude_total;
+    uint32_t	end_reason;	/* 1: carrier lost, 2: end of stream        */
+    uint32_t	reserved;
+} mifsk_episode;
+
+#define MIFSK_STREAM_FRAMES_TRUNCATED	1u
+#define MIFSK_STREAM_EPISODES_TRUNCATED	2u
+
+typedef struct mifsk_demod_io {
+    /* inputs */
+    const float		*d_samples;	/* nstreams rows, stream-major       */
+    size_t		stream_stride;	/* floats between rows (16 B aligned)*/
+    const uint32_t	*d_nsamples;	/* per stream; NULL -> all = nsamples*/
+    uint32_t		nsamples;
+    int			nstreams;
+    /* outputs (any of bytes/bits/frames may be NULL) */
+    uint8_t		*d_bytes;	/* [nstreams][frames_cap]: low 8 data
+					   bits of every unsuppressed frame  */
+    uint32_t		*d_nbytes;	/* [nstreams]                        */
+    uint64_t		*d_bits;	/* [nstreams][frames_cap] data bits of
+					   every frame incl. suppressed ones */
+    mifsk_frame		*d_frames;	/* [nstreams][frames_cap]            */
+    uint32_t		*d_nframes;	/* [nstreams] frames in loop order   */
+    size_t		frames_cap;
+    mifsk_episode	*d_episodes;	/* [nstreams][episodes_cap]          */
+    uint32_t		*d_nepisodes;	/* [nstreams]                        */
+    size_t		episodes_cap;
+    uint32_t		*d_status;	/* [nstreams] MIFSK_STREAM_* or NULL */
+} mifsk_demod_io;
+
+int mifsk_demod_batch( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
+	const mifsk_demod_io *io, void *stream );
+
+/* Same, for HOST pointers in `io` (all fields, d_ prefix notwithstanding):
+ * copies in, runs mifsk_demod_batch, copies out, synchronises. */
+int mifsk_demod_batch_host( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
+	const mifsk_demod_io *io );
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* MIFSK_H */

@@ -1,0 +1,45 @@
+"""Loader for tests/golden/*.npz (made by tests/golden/make_golden.py from the
+reference itself)."""
+import glob
+import os
+
+import numpy as np
+
+import _oracle as O
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def names():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+_INT_KEYS = {"sample_rate", "n_data_bits", "nstartbits"}
+_FLOAT_KEYS = {"mark_f", "space_f", "band_width", "nstopbits"}
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+    kw = {}
+    for k, v in zip(z["cfg_keys"].tolist(), z["cfg_vals"].tolist()):
+        if k in _INT_KEYS:
+            kw[k] = int(v)
+        elif k in _FLOAT_KEYS:
+            kw[k] = float(v)
+        else:
+            kw[k] = v
+    s = z["samples"]
+    if s.dtype == np.int16:
+        x = s.astype(np.float32) / np.float32(32768.0)   # libsndfile S16 -> float
+    else:
+        x = s.astype(np.float32)
+    return {
+        "name": name,
+        "samples": x,
+        "sample_rate": int(z["sample_rate"]),
+        "payload": z["payload"].tobytes(),
+        "stdout": z["stdout"].tobytes(),
+        "nocarrier": [str(s) for s in z["nocarrier"].tolist()],
+        "trace": z["trace"],
+        "cfg_kwargs": kw,
+    }

@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REFERENCE ITSELF (oracle/_ref).
+
+Run in the build container (needs oracle/_ref, i.e. /root/reference present):
+
+    python tests/golden/make_golden.py
+
+For every case (one per family of reference tests, tests/*.test) it
+  1. transmits a short payload with `minimodem_ref --tx --file x.wav ...`
+  2. receives it with `minimodem_ref --rx --file x.wav ...`
+  3. drives the reference's own fsk_find_frame() (libfsk_ref.so = unmodified
+     src/fsk.c + FFT shim) over a deterministic set of search windows
+and stores: the audio samples (exactly as written by the reference TX), the
+decoded stdout bytes, the "### NOCARRIER" statistics lines, and the
+find_frame call trace (arguments + outputs).  The oracle restatement and the
+HIP path are both checked against these files; the files are small on purpose
+(short payloads) -- the full 500-byte reference payloads are exercised live
+against oracle/_ref by tests/test_oracle_vs_reference.py where it exists.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import _oracle as O  # noqa: E402
+
+ASCII_PAYLOAD = (b"The quick brown fox jumps over the lazy dog 0123456789 "
+                 b"!\"#$%&'()*+,-./:;<=>?@[\\]^_`{|}~ MI355X fsk\n")
+BAUDOT_PAYLOAD = b"THE QUICK BROWN FOX JUMPS OVER THE LAZY DOG 0123456789\n"
+
+# name, payload, tx args, rx args, oracle_config kwargs
+CASES = [
+    ("t01_1200", ASCII_PAYLOAD, ["1200"], ["1200"], dict(baudmode="1200")),
+    ("t02_300", ASCII_PAYLOAD[:48], ["300"], ["300"], dict(baudmode="300")),
+    ("t03_rtty", BAUDOT_PAYLOAD[:24], ["rtty"], ["rtty"], dict(baudmode="rtty")),
+    ("t05_12000", ASCII_PAYLOAD, ["12000"], ["12000"], dict(baudmode="12000")),
+    ("t06_1200_float", ASCII_PAYLOAD, ["1200", "--float-samples"], ["1200"],
+     dict(baudmode="1200")),
+    ("t07_1200_nolut", ASCII_PAYLOAD, ["1200", "--lut=0"], ["1200"], dict(baudmode="1200")),
+    ("t08_1200_lut16", ASCII_PAYLOAD, ["1200", "--lut=16"], ["1200"], dict(baudmode="1200")),
+    ("t10_perfect", ASCII_PAYLOAD,
+     "1200 --samplerate 24000 -M 1200 -S 2400".split(),
+     "1200 --samplerate 24000 -M 1200 -S 2400".split(),
+     dict(baudmode="1200", sample_rate=24000, mark_f=1200, space_f=2400)),
+    ("t13_perfect_nolut_float", ASCII_PAYLOAD,
+     "1200 --samplerate 24000 -M 1200 -S 2400 --lut=0 --float-samples".split(),
+     "1200 --samplerate 24000 -M 1200 -S 2400".split(),
+     dict(baudmode="1200", sample_rate=24000, mark_f=1200, space_f=2400)),
+    ("t14_perfect_lut16_float", ASCII_PAYLOAD,
+     "1200 --samplerate 24000 -M 1200 -S 2400 --lut=16 --float-samples".split(),
+     "1200 --samplerate 24000 -M 1200 -S 2400".split(),
+     dict(baudmode="1200", sample_rate=24000, mark_f=1200, space_f=2400)),
+    ("t21_slop_308", ASCII_PAYLOAD[:48], ["308"], ["300"], dict(baudmode="300")),
+    ("t21_slop_292", ASCII_PAYLOAD[:48], ["292"], ["300"], dict(baudmode="300")),
+    ("t30_ampl_0p3", ASCII_PAYLOAD, ["--volume", "0.30", "1200"], ["1200"],
+     dict(baudmode="1200")),
+    ("t60_7bit", ASCII_PAYLOAD, ["1200", "-7"], ["1200", "-7"],
+     dict(baudmode="1200", n_data_bits=7)),
+    ("t80_same", ASCII_PAYLOAD, ["same"], ["same"], dict(baudmode="same")),
+    ("t81_tdd", BAUDOT_PAYLOAD[:24], ["tdd"], ["tdd"], dict(baudmode="tdd")),
+]
+
+
+def find_frame_trace(cfg, x, max_calls=24):
+    """Call the reference's fsk_find_frame on windows laid out the way main()
+    lays them out (coarse no-carrier, coarse carrier, fine), at deterministic
+    offsets spread over the stream."""
+    lib = O.ref_lib()
+    plan = lib.fsk_plan_new(float(cfg.sample_rate), cfg.mark_f, cfg.space_f, cfg.band_width)
+    assert plan
+    pad = np.zeros(int(cfg.expect_nsamples) + 2 * int(cfg.try_max[0]) + 64, np.float32)
+    xp = np.concatenate([x, pad])
+    n = x.shape[0]
+    span = int(cfg.expect_nsamples) + int(cfg.try_max[0])
+    rng = np.random.default_rng(20260923)
+    offs = sorted(set(int(v) for v in rng.integers(0, max(1, n - span), size=max_calls)))
+    rows = []
+    for i, off in enumerate(offs):
+        mode = i % 3
+        if mode == 0:      # coarse, no carrier, sync string
+            ci, step, limit, expect = 0, cfg.try_step[0], cfg.search_limit, cfg.expect_sync
+        elif mode == 1:    # coarse, carrier, data string
+            ci, step, limit, expect = 1, cfg.try_step[1], cfg.search_limit, cfg.expect_data
+        else:              # fine rescan
+            ci, step, limit, expect = 1, cfg.try_step_fine[1], float("inf"), cfg.expect_data
+        first, tmax = int(cfg.try_first[ci]), int(cfg.try_max[ci])
+        conf, bits, ampl, start = O.ref_find_frame(
+            plan, xp[off:], int(cfg.expect_nsamples), first, tmax, int(step),
+            limit, expect)
+        rows.append((off, first, tmax, int(step), limit, 1 if expect == cfg.expect_sync and
+                     cfg.expect_sync != cfg.expect_data else 0, conf, bits, ampl, start))
+    lib.fsk_plan_destroy(plan)
+    dt = np.dtype([("offset", "<u8"), ("first", "<u4"), ("max", "<u4"), ("step", "<u4"),
+                   ("limit", "<f4"), ("use_sync", "<u4"), ("confidence", "<f4"),
+                   ("bits", "<u8"), ("amplitude", "<f4"), ("start", "<u4")])
+    return np.array(rows, dtype=dt)
+
+
+def main():
+    assert O.have_ref(), "oracle/_ref missing: run `make -C oracle` where /root/reference exists"
+    for name, payload, tx, rx, kw in CASES:
+        wav = O.tmp_wav()
+        try:
+            O.ref_tx(payload, tx, wav)
+            out, err = O.ref_rx(wav, rx)
+            with open(wav, "rb") as f:
+                raw = f.read()
+            sr, x = O.read_wav(wav)
+        finally:
+            os.unlink(wav)
+        is_float = "--float-samples" in tx
+        # store the samples in their on-disk encoding (S16 files stay 2 B/sample)
+        if is_float:
+            stored = x.astype("<f4")
+        else:
+            stored = np.frombuffer(raw[44:], dtype="<i2").copy()
+            assert np.array_equal(stored.astype(np.float32) / np.float32(32768.0), x)
+        cfg = O.oracle_config(**kw)
+        assert cfg.sample_rate == sr
+        trace = find_frame_trace(cfg, x)
+        stats = [l for l in err.splitlines() if l.startswith("### NOCARRIER")]
+        carriers = [l for l in err.splitlines() if l.startswith("### CARRIER")]
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(
+            path, samples=stored, sample_rate=np.int64(sr),
+            payload=np.frombuffer(payload, np.uint8),
+            stdout=np.frombuffer(out, np.uint8),
+            nocarrier=np.array(stats), carrier=np.array(carriers),
+            trace=trace,
+            tx_args=np.array(tx), rx_args=np.array(rx),
+            cfg_keys=np.array(list(kw.keys())),
+            cfg_vals=np.array([str(v) for v in kw.values()]))
+        print("%-28s %8d samples  %4d bytes out  %s  (%d KiB)" % (
+            name, x.shape[0], len(out), stats[-1] if stats else "-",
+            os.path.getsize(path) // 1024))
+
+
+if __name__ == "__main__":
+    main()
