@@ -1,0 +1,314 @@
+"""minimodem_amd -- MI355X-native batched FSK demodulator behind minimodem's
+fsk.h API.
+
+The signal path lives in libmifsk.so (hand-written HIP for gfx950, C ABI in
+include/fsk.h + include/mifsk.h).  This package is the thin host-side mirror
+used by the tests, the benchmark and Python callers: it marshals arguments,
+uses PyTorch only for device memory / streams / torch.distributed, and raises
+if the native library is missing -- there is no fallback implementation.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import _lib
+from ._lib import ModemArgs, RxConfig  # noqa: F401
+
+__all__ = ["build", "rx_config", "Context", "demod_batch", "find_frame_batch",
+           "LegacyPlan", "synthesize", "FRAME_DTYPE", "EPISODE_DTYPE",
+           "gather_bytes", "shard_range"]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+FRAME_DTYPE = np.dtype([("bits", "<u8"), ("start", "<u8"), ("confidence", "<f4"),
+                        ("amplitude", "<f4"), ("flags", "<u4"), ("reserved", "<u4")])
+EPISODE_DTYPE = np.dtype([("carrier_nsamples", "<u8"), ("first_frame", "<u4"),
+                          ("nframes", "<u4"), ("confidence_total", "<f4"),
+                          ("amplitude_total", "<f4"), ("end_reason", "<u4"),
+                          ("reserved", "<u4")])
+SEARCH_DTYPE = np.dtype([("sample_offset", "<u8"), ("navail", "<u4"), ("try_first", "<u4"),
+                         ("try_max", "<u4"), ("try_step", "<u4"), ("search_limit", "<f4"),
+                         ("use_sync_string", "<u4")])
+RESULT_DTYPE = np.dtype([("bits", "<u8"), ("confidence", "<f4"), ("amplitude", "<f4"),
+                         ("frame_start", "<u4"), ("n_positions", "<u4")])
+assert SEARCH_DTYPE.itemsize == 32 and RESULT_DTYPE.itemsize == 24
+
+
+def build(force=False):
+    """Compile libmifsk.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force and os.path.exists(_lib.LIB_PATH):
+        os.unlink(_lib.LIB_PATH)
+    subprocess.run(["make", "-s", "-C", os.path.join(_HERE, "csrc")], check=True)
+    return _lib.LIB_PATH
+
+
+def rx_config(baudmode="1200", **opts):
+    """The --rx command line as a derived configuration
+    (mifsk_rx_config_init; reference src/minimodem.c:819-965,1037-1131)."""
+    lib = _lib.load()
+    a = ModemArgs()
+    lib.mifsk_modem_args_default(C.byref(a))
+    a.baudmode = str(baudmode).encode()
+    if "sync_byte" in opts:
+        a.have_sync_byte = 1
+    for k, v in opts.items():
+        if not hasattr(a, k):
+            raise TypeError("unknown modem option %r" % k)
+        setattr(a, k, v)
+    cfg = RxConfig()
+    rc = lib.mifsk_rx_config_init(C.byref(cfg), C.byref(a))
+    if rc != 0:
+        raise ValueError("mifsk_rx_config_init failed: %d" % rc)
+    cfg._keepalive = a
+    return cfg
+
+
+class Context:
+    """A device context (twiddle tables etc.); one per process/GPU."""
+
+    def __init__(self, device=-1):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        rc = self._lib.mifsk_ctx_create(C.byref(h), int(device))
+        if rc != 0:
+            raise RuntimeError("mifsk_ctx_create failed: %d (no gfx950 HIP device? "
+                               "this package has no CPU path)" % rc)
+        self.handle = h
+
+    @property
+    def device_name(self):
+        return self._lib.mifsk_ctx_device_name(self.handle).decode()
+
+    def close(self):
+        if self.handle:
+            self._lib.mifsk_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _stream_ptr(torch, stream):
+    if stream is None:
+        stream = torch.cuda.current_stream()
+    return C.c_void_p(stream.cuda_stream)
+
+
+def max_frames(cfg, nsamples):
+    return int(_lib.load().mifsk_max_frames(C.byref(cfg), int(nsamples)))
+
+
+def demod_batch(ctx, cfg, samples, nsamples=None, want=("bytes", "episodes"),
+                frames_cap=None, episodes_cap=8, stream=None, out=None):
+    """Run the receive loop over a batch of streams resident in HBM.
+
+    samples : torch.float32 CUDA tensor [nstreams, stride] (stride % 4 == 0)
+    nsamples: optional torch.int32/uint32 CUDA tensor [nstreams]; default: stride
+    Returns a dict of CUDA tensors (no synchronisation is performed).
+    `out` may be a dict returned by a previous call with the same shapes, to
+    reuse its buffers (nothing is allocated inside the timed region then).
+    """
+    torch = _torch()
+    lib = _lib.load()
+    assert samples.is_cuda and samples.dtype == torch.float32 and samples.dim() == 2
+    assert samples.stride(1) == 1
+    nstreams, width = samples.shape
+    stride = samples.stride(0)
+    n_uniform = int(width)
+    if frames_cap is None:
+        frames_cap = max_frames(cfg, n_uniform)
+    dev = samples.device
+    if out is None:
+        out = {}
+        out["nframes"] = torch.zeros(nstreams, dtype=torch.int32, device=dev)
+        out["status"] = torch.zeros(nstreams, dtype=torch.int32, device=dev)
+        if "bytes" in want:
+            out["bytes"] = torch.zeros((nstreams, frames_cap), dtype=torch.uint8, device=dev)
+            out["nbytes"] = torch.zeros(nstreams, dtype=torch.int32, device=dev)
+        if "bits" in want:
+            out["bits"] = torch.zeros((nstreams, frames_cap), dtype=torch.int64, device=dev)
+        if "frames" in want:
+            out["frames"] = torch.zeros((nstreams, frames_cap, FRAME_DTYPE.itemsize),
+                                        dtype=torch.uint8, device=dev)
+        if "episodes" in want:
+            out["episodes"] = torch.zeros((nstreams, episodes_cap, EPISODE_DTYPE.itemsize),
+                                          dtype=torch.uint8, device=dev)
+            out["nepisodes"] = torch.zeros(nstreams, dtype=torch.int32, device=dev)
+
+    def ptr(name):
+        t = out.get(name)
+        return C.c_void_p(t.data_ptr()) if t is not None else None
+
+    io = _lib.DemodIO()
+    io.d_samples = samples.data_ptr()
+    io.stream_stride = stride
+    io.d_nsamples = nsamples.data_ptr() if nsamples is not None else None
+    io.nsamples = n_uniform
+    io.nstreams = nstreams
+    io.d_bytes = ptr("bytes")
+    io.d_nbytes = ptr("nbytes")
+    io.d_bits = ptr("bits")
+    io.d_frames = ptr("frames")
+    io.d_nframes = ptr("nframes")
+    io.frames_cap = frames_cap
+    io.d_episodes = ptr("episodes")
+    io.d_nepisodes = ptr("nepisodes")
+    io.episodes_cap = episodes_cap
+    io.d_status = ptr("status")
+    rc = lib.mifsk_demod_batch(ctx.handle, C.byref(cfg), C.byref(io), _stream_ptr(torch, stream))
+    if rc != 0:
+        raise RuntimeError("mifsk_demod_batch failed: %d" % rc)
+    return out
+
+
+def results_to_host(out):
+    """Copy a demod_batch() result to numpy (synchronises)."""
+    res = {}
+    for k, t in out.items():
+        a = t.cpu().numpy()
+        if k == "frames":
+            a = a.view(FRAME_DTYPE).reshape(a.shape[0], a.shape[1])
+        elif k == "episodes":
+            a = a.view(EPISODE_DTYPE).reshape(a.shape[0], a.shape[1])
+        elif k == "bits":
+            a = a.view(np.uint64)
+        res[k] = a
+    return res
+
+
+def find_frame_batch(ctx, cfg, samples, problems, stream=None):
+    """N independent fsk_find_frame() problems over a flat CUDA float buffer.
+    `problems` is a numpy array of SEARCH_DTYPE; returns numpy RESULT_DTYPE."""
+    torch = _torch()
+    lib = _lib.load()
+    assert samples.is_cuda and samples.dtype == torch.float32
+    problems = np.ascontiguousarray(problems, dtype=SEARCH_DTYPE)
+    n = problems.shape[0]
+    d_prob = torch.from_numpy(problems.view(np.uint8).reshape(-1).copy()).to(samples.device)
+    d_res = torch.zeros(n * RESULT_DTYPE.itemsize, dtype=torch.uint8, device=samples.device)
+    rc = lib.mifsk_find_frame_batch(ctx.handle, C.byref(cfg), C.c_void_p(samples.data_ptr()),
+                                    C.c_void_p(d_prob.data_ptr()), C.c_void_p(d_res.data_ptr()),
+                                    n, _stream_ptr(torch, stream))
+    if rc != 0:
+        raise RuntimeError("mifsk_find_frame_batch failed: %d" % rc)
+    return d_res.cpu().numpy().view(RESULT_DTYPE)
+
+
+class LegacyPlan:
+    """The reference's fsk.h API (include/fsk.h), called through the C ABI with
+    host buffers exactly as src/minimodem.c calls it."""
+
+    def __init__(self, sample_rate, f_mark, f_space, filter_bw):
+        self._lib = _lib.load()
+        self.p = self._lib.fsk_plan_new(sample_rate, f_mark, f_space, filter_bw)
+        if not self.p:
+            raise OSError(C.get_errno(), "fsk_plan_new failed")
+
+    def __getattr__(self, name):
+        return getattr(self.p.contents, name)
+
+    def find_frame(self, samples, frame_nsamples, try_first, try_max, try_step, limit, expect):
+        samples = np.ascontiguousarray(samples, dtype=np.float32)
+        bits, ampl, start = C.c_ulonglong(0), C.c_float(0), C.c_uint(0)
+        conf = self._lib.fsk_find_frame(self.p, samples.ctypes.data, frame_nsamples, try_first,
+                                        try_max, try_step, C.c_float(limit),
+                                        expect.encode() if isinstance(expect, str) else expect,
+                                        C.byref(bits), C.byref(ampl), C.byref(start))
+        return float(conf), int(bits.value), float(ampl.value), int(start.value)
+
+    def detect_carrier(self, samples, min_mag_threshold):
+        samples = np.ascontiguousarray(samples, dtype=np.float32)
+        return int(self._lib.fsk_detect_carrier(self.p, samples.ctypes.data, samples.shape[0],
+                                                C.c_float(min_mag_threshold)))
+
+    def set_tones_by_bandshift(self, b_mark, b_shift):
+        self._lib.fsk_set_tones_by_bandshift(self.p, b_mark, b_shift)
+
+    def close(self):
+        if self.p:
+            self._lib.fsk_plan_destroy(self.p)
+            self.p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def synthesize(cfg, words, lut=4096, amplitude=1.0, leading_silence=0, s16=False):
+    """FSK audio for `words` exactly as `minimodem --tx --file` writes it
+    (host-side generator, csrc/mifsk_tx.cpp).  Returns float32 numpy."""
+    lib = _lib.load()
+    words = np.ascontiguousarray(np.frombuffer(bytes(words), dtype=np.uint8)
+                                 if isinstance(words, (bytes, bytearray)) else words,
+                                 dtype=np.uint8)
+    n = lib.mifsk_tx_synthesize(C.byref(cfg), words.ctypes.data, words.shape[0], lut,
+                                C.c_float(amplitude), leading_silence, 1 if s16 else 0,
+                                None, 0)
+    if n < 0:
+        raise ValueError("mifsk_tx_synthesize failed: %d" % n)
+    out = np.zeros(n, dtype=np.float32)
+    lib.mifsk_tx_synthesize(C.byref(cfg), words.ctypes.data, words.shape[0], lut,
+                            C.c_float(amplitude), leading_silence, 1 if s16 else 0,
+                            out.ctypes.data, n)
+    return out
+
+
+# ---------------------------------------------------------------------------
+# multi-GPU: streams are independent, so ranks own contiguous stream ranges and
+# the only exchange is a gather of decoded bytes (RCCL over xGMI on GPUs; the
+# same code runs over gloo on CPU tensors in the tests).
+# ---------------------------------------------------------------------------
+
+def shard_range(nstreams, rank, world):
+    """Contiguous, balanced [lo, hi) stream range of `rank`."""
+    q, r = divmod(nstreams, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def gather_bytes(local_bytes, local_nbytes, dst=0, group=None):
+    """Gather every rank's decoded bytes ([n_local, cap] uint8 + [n_local] int32
+    counts) to rank `dst`.  Returns (bytes, nbytes) lists on dst, None elsewhere."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if world == 1:
+        return [local_bytes], [local_nbytes]
+    torch = _torch()
+    shape = torch.tensor([local_bytes.shape[0], local_bytes.shape[1]], dtype=torch.int64,
+                         device=local_bytes.device)
+    shapes = [torch.zeros_like(shape) for _ in range(world)]
+    dist.all_gather(shapes, shape, group=group)
+    if rank == dst:
+        bufs = [torch.empty((int(s[0]), int(s[1])), dtype=torch.uint8, device=local_bytes.device)
+                for s in shapes]
+        cnts = [torch.empty(int(s[0]), dtype=torch.int32, device=local_bytes.device)
+                for s in shapes]
+        bufs[dst] = local_bytes
+        cnts[dst] = local_nbytes
+        reqs = []
+        for r in range(world):
+            if r == dst:
+                continue
+            reqs.append(dist.P2POp(dist.irecv, bufs[r], r, group))
+            reqs.append(dist.P2POp(dist.irecv, cnts[r], r, group))
+        for w in dist.batch_isend_irecv(reqs):
+            w.wait()
+        return bufs, cnts
+    reqs = [dist.P2POp(dist.isend, local_bytes.contiguous(), dst, group),
+            dist.P2POp(dist.isend, local_nbytes.contiguous(), dst, group)]
+    for w in dist.batch_isend_irecv(reqs):
+        w.wait()
+    return None, None

@@ -1,0 +1,210 @@
+"""ctypes binding of libmifsk.so (the C ABI declared in include/fsk.h and
+include/mifsk.h).  The library is built in-tree by `minimodem_amd.build()` /
+`__graft_entry__.build()`; if it is missing or cannot be loaded this module
+raises -- there is no Python or CPU fallback for the signal path."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmifsk.so")
+MAX_BITS = 64
+
+
+class ModemArgs(C.Structure):
+    _fields_ = [
+        ("baudmode", C.c_char_p),
+        ("sample_rate", C.c_uint),
+        ("mark_f", C.c_float),
+        ("space_f", C.c_float),
+        ("band_width", C.c_float),
+        ("n_data_bits", C.c_int),
+        ("baudot", C.c_int),
+        ("nstartbits", C.c_int),
+        ("nstopbits", C.c_float),
+        ("invert_start_stop", C.c_int),
+        ("inverted_freqs", C.c_int),
+        ("msb_first", C.c_int),
+        ("have_sync_byte", C.c_int),
+        ("sync_byte", C.c_longlong),
+        ("confidence_threshold", C.c_float),
+        ("search_limit", C.c_float),
+        ("binary_output", C.c_int),
+        ("binary_raw_nbits", C.c_int),
+        ("rx_one", C.c_int),
+        ("auto_carrier_threshold", C.c_float),
+    ]
+
+
+class RxConfig(C.Structure):
+    _fields_ = [
+        ("sample_rate", C.c_uint),
+        ("data_rate", C.c_float),
+        ("mark_f", C.c_float),
+        ("space_f", C.c_float),
+        ("band_width", C.c_float),
+        ("n_data_bits", C.c_uint),
+        ("nstartbits", C.c_int),
+        ("nstopbits", C.c_float),
+        ("invert_start_stop", C.c_int),
+        ("msb_first", C.c_int),
+        ("do_rx_sync", C.c_int),
+        ("sync_byte", C.c_ulonglong),
+        ("decoder", C.c_int),
+        ("rx_one", C.c_int),
+        ("confidence_threshold", C.c_float),
+        ("search_limit", C.c_float),
+        ("auto_carrier_threshold", C.c_float),
+        ("autodetect_shift", C.c_int),
+        ("inverted_freqs", C.c_int),
+        ("fftsize", C.c_int),
+        ("nbands", C.c_uint),
+        ("b_mark", C.c_uint),
+        ("b_space", C.c_uint),
+        ("frame_n_bits", C.c_uint),
+        ("nsamples_per_bit", C.c_float),
+        ("nsamples_overscan", C.c_uint),
+        ("frame_nsamples", C.c_uint),
+        ("expect_n_bits", C.c_uint),
+        ("expect_nsamples", C.c_uint),
+        ("expect_data", C.c_char * (MAX_BITS + 4)),
+        ("expect_sync", C.c_char * (MAX_BITS + 4)),
+        ("samplebuf_size", C.c_uint),
+        ("try_first", C.c_uint * 2),
+        ("try_max", C.c_uint * 2),
+        ("try_step", C.c_uint * 2),
+        ("try_step_fine", C.c_uint * 2),
+        ("find_samples_per_bit", C.c_float),
+        ("bit_nsamples", C.c_uint),
+        ("bit_offset", C.c_uint * MAX_BITS),
+    ]
+
+    def as_dict(self):
+        out = {}
+        for name, _t in self._fields_:
+            v = getattr(self, name)
+            if isinstance(v, bytes):
+                v = v.decode()
+            elif hasattr(v, "__len__"):
+                v = list(v)
+            out[name] = v
+        return out
+
+
+class Search(C.Structure):
+    _fields_ = [
+        ("sample_offset", C.c_uint64),
+        ("navail", C.c_uint32),
+        ("try_first", C.c_uint32),
+        ("try_max", C.c_uint32),
+        ("try_step", C.c_uint32),
+        ("search_limit", C.c_float),
+        ("use_sync_string", C.c_uint32),
+    ]
+
+
+class SearchResult(C.Structure):
+    _fields_ = [
+        ("bits", C.c_uint64),
+        ("confidence", C.c_float),
+        ("amplitude", C.c_float),
+        ("frame_start", C.c_uint32),
+        ("n_positions", C.c_uint32),
+    ]
+
+
+class DemodIO(C.Structure):
+    _fields_ = [
+        ("d_samples", C.c_void_p),
+        ("stream_stride", C.c_size_t),
+        ("d_nsamples", C.c_void_p),
+        ("nsamples", C.c_uint32),
+        ("nstreams", C.c_int),
+        ("d_bytes", C.c_void_p),
+        ("d_nbytes", C.c_void_p),
+        ("d_bits", C.c_void_p),
+        ("d_frames", C.c_void_p),
+        ("d_nframes", C.c_void_p),
+        ("frames_cap", C.c_size_t),
+        ("d_episodes", C.c_void_p),
+        ("d_nepisodes", C.c_void_p),
+        ("episodes_cap", C.c_size_t),
+        ("d_status", C.c_void_p),
+    ]
+
+
+class FskPlan(C.Structure):
+    """struct fsk_plan, include/fsk.h (layout of reference src/fsk.h:30-46)."""
+    _fields_ = [
+        ("sample_rate", C.c_float), ("f_mark", C.c_float), ("f_space", C.c_float),
+        ("filter_bw", C.c_float), ("fftsize", C.c_int), ("nbands", C.c_uint),
+        ("band_width", C.c_float), ("b_mark", C.c_uint), ("b_space", C.c_uint),
+        ("fftplan", C.c_void_p), ("fftin", C.c_void_p), ("fftout", C.c_void_p),
+    ]
+
+
+assert C.sizeof(FskPlan) == 64 and FskPlan.fftplan.offset == 40
+assert C.sizeof(Search) == 32 and C.sizeof(SearchResult) == 24
+
+# every symbol include/*.h declares
+EXPORTS = [
+    "fsk_plan_new", "fsk_plan_destroy", "fsk_find_frame", "fsk_detect_carrier",
+    "fsk_set_tones_by_bandshift",
+    "mifsk_modem_args_default", "mifsk_rx_config_init", "mifsk_max_frames",
+    "mifsk_stream_padding", "mifsk_ctx_create", "mifsk_ctx_destroy",
+    "mifsk_ctx_device_name", "mifsk_abi_version", "mifsk_find_frame_batch",
+    "mifsk_demod_batch", "mifsk_demod_batch_host",
+    "mifsk_tx_tone_init", "mifsk_tx_synthesize",
+]
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  minimodem_amd has no fallback path." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.mifsk_modem_args_default.argtypes = [C.POINTER(ModemArgs)]
+    lib.mifsk_rx_config_init.restype = C.c_int
+    lib.mifsk_rx_config_init.argtypes = [C.POINTER(RxConfig), C.POINTER(ModemArgs)]
+    lib.mifsk_max_frames.restype = C.c_size_t
+    lib.mifsk_max_frames.argtypes = [C.POINTER(RxConfig), C.c_size_t]
+    lib.mifsk_stream_padding.restype = C.c_size_t
+    lib.mifsk_stream_padding.argtypes = [C.POINTER(RxConfig)]
+    lib.mifsk_ctx_create.restype = C.c_int
+    lib.mifsk_ctx_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    lib.mifsk_ctx_destroy.argtypes = [C.c_void_p]
+    lib.mifsk_ctx_device_name.restype = C.c_char_p
+    lib.mifsk_ctx_device_name.argtypes = [C.c_void_p]
+    lib.mifsk_abi_version.restype = C.c_int
+    lib.mifsk_find_frame_batch.restype = C.c_int
+    lib.mifsk_find_frame_batch.argtypes = [C.c_void_p, C.POINTER(RxConfig), C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.mifsk_demod_batch.restype = C.c_int
+    lib.mifsk_demod_batch.argtypes = [C.c_void_p, C.POINTER(RxConfig), C.POINTER(DemodIO),
+                                      C.c_void_p]
+    lib.mifsk_demod_batch_host.restype = C.c_int
+    lib.mifsk_demod_batch_host.argtypes = [C.c_void_p, C.POINTER(RxConfig), C.POINTER(DemodIO)]
+    lib.fsk_plan_new.restype = C.POINTER(FskPlan)
+    lib.fsk_plan_new.argtypes = [C.c_float] * 4
+    lib.fsk_plan_destroy.argtypes = [C.c_void_p]
+    lib.fsk_find_frame.restype = C.c_float
+    lib.fsk_find_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint,
+                                   C.c_uint, C.c_float, C.c_char_p,
+                                   C.POINTER(C.c_ulonglong), C.POINTER(C.c_float),
+                                   C.POINTER(C.c_uint)]
+    lib.fsk_detect_carrier.restype = C.c_int
+    lib.fsk_detect_carrier.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_float]
+    lib.fsk_set_tones_by_bandshift.argtypes = [C.c_void_p, C.c_uint, C.c_int]
+    lib.mifsk_tx_tone_init.restype = C.c_int
+    lib.mifsk_tx_tone_init.argtypes = [C.c_uint, C.c_float]
+    lib.mifsk_tx_synthesize.restype = C.c_long
+    lib.mifsk_tx_synthesize.argtypes = [C.POINTER(RxConfig), C.c_void_p, C.c_size_t,
+                                        C.c_uint, C.c_float, C.c_uint, C.c_int,
+                                        C.c_void_p, C.c_size_t]
+    _lib = lib
+    return lib

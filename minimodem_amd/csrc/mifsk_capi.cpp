@@ -1,0 +1,536 @@
+// mifsk_capi.cpp -- the C ABI of libmifsk.so (include/fsk.h, include/mifsk.h).
+//
+// Host-side glue only: contexts, twiddle tables, argument marshalling, and the
+// reference-compatible five-function API layered over the same kernels as the
+// batch entry points.  There is no CPU implementation of the signal path in
+// this library: every entry point that produces a result launches a HIP kernel,
+// and context creation fails with -ENODEV when no gfx950 device is available.
+#include <hip/hip_runtime.h>
+
+#include <cerrno>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "fsk.h"
+#include "mifsk.h"
+#include "mifsk_device.h"
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+namespace mifsk {
+
+void fill_devcfg( DevCfg &d, const mifsk_rx_config &c )
+{
+    std::memset(&d, 0, sizeof(d));
+    d.n_bits = c.expect_n_bits;
+    d.bit_nsamples = c.bit_nsamples;
+    d.last_reach = c.bit_offset[c.expect_n_bits - 1] + c.bit_nsamples;
+    d.magscalar = 2.0f / (float)c.bit_nsamples;		// fsk.c:132
+    d.frame_nsamples = c.frame_nsamples;
+    d.expect_nsamples = c.expect_nsamples;
+    d.overscan = c.nsamples_overscan;
+    for ( int i = 0; i < 2; i++ ) {
+	d.try_first[i] = c.try_first[i];
+	d.try_max[i] = c.try_max[i];
+	d.try_step[i] = c.try_step[i];
+	d.try_step_fine[i] = c.try_step_fine[i];
+    }
+    d.conf_threshold = c.confidence_threshold;
+    d.search_limit = c.search_limit;
+    d.n_data_bits = c.n_data_bits;
+    d.nstartbits = (uint32_t)c.nstartbits;
+    d.has_stopbits = c.nstopbits != 0.0f ? 1u : 0u;
+    d.msb_first = c.msb_first ? 1u : 0u;
+    d.do_rx_sync = c.do_rx_sync ? 1u : 0u;
+    d.rx_one = c.rx_one ? 1u : 0u;
+    d.sync_byte = c.sync_byte;
+    // odd row pitch => lanes one bit apart never share an LDS bank
+    d.skew = ( c.bit_nsamples & 1u ) ? 0u : 1u;
+    for ( unsigned k = 0; k < c.expect_n_bits; k++ ) {
+	d.bit_offset[k] = c.bit_offset[k];
+	for ( int s = 0; s < 2; s++ ) {
+	    const char ch = ( s ? c.expect_sync : c.expect_data )[k];
+	    d.expect[s][k] = ch == 'd' ? 2 : (uint8_t)( ch - '0' );
+	}
+    }
+}
+
+} // namespace mifsk
+
+using mifsk::DevCfg;
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+
+struct TwKey {
+    unsigned fftsize, b_mark, b_space, bit_nsamples;
+    bool operator==( const TwKey &o ) const
+    {
+	return fftsize == o.fftsize && b_mark == o.b_mark && b_space == o.b_space
+	    && bit_nsamples == o.bit_nsamples;
+    }
+};
+
+struct TwEntry {
+    TwKey	key;
+    double	*d_tw;
+};
+
+struct mifsk_ctx {
+    int			device;
+    char		name[256];
+    std::mutex		lock;
+    std::vector<TwEntry>	tables;
+    // spectrum table for fsk_detect_carrier
+    unsigned		cs_fftsize;
+    double		*d_cs;
+};
+
+#define HIP_OK(call)	do { hipError_t e_ = (call); if ( e_ != hipSuccess ) { \
+	fprintf(stderr, "mifsk: %s failed: %s\n", #call, hipGetErrorString(e_)); \
+	return -EIO; } } while (0)
+
+extern "C" int mifsk_abi_version( void ) { return MIFSK_ABI_VERSION; }
+
+extern "C" int mifsk_ctx_create( mifsk_ctx **out, int device )
+{
+    if ( !out )
+	return -EINVAL;
+    *out = nullptr;
+    int ndev = 0;
+    if ( hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 ) {
+	fprintf(stderr, "mifsk: no HIP device available (this library has no CPU path)\n");
+	return -ENODEV;
+    }
+    if ( device >= 0 ) {
+	if ( device >= ndev )
+	    return -ENODEV;
+	HIP_OK(hipSetDevice(device));
+    } else {
+	HIP_OK(hipGetDevice(&device));
+    }
+    hipDeviceProp_t prop;
+    HIP_OK(hipGetDeviceProperties(&prop, device));
+    if ( std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 ) {
+	fprintf(stderr, "mifsk: device %d is %s; the kernels are built for gfx950 only\n",
+		device, prop.gcnArchName);
+	return -ENODEV;
+    }
+    mifsk_ctx *ctx = new (std::nothrow) mifsk_ctx();
+    if ( !ctx )
+	return -ENOMEM;
+    ctx->device = device;
+    std::snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
+    ctx->cs_fftsize = 0;
+    ctx->d_cs = nullptr;
+    *out = ctx;
+    return 0;
+}
+
+extern "C" void mifsk_ctx_destroy( mifsk_ctx *ctx )
+{
+    if ( !ctx )
+	return;
+    for ( TwEntry &e : ctx->tables )
+	(void)hipFree(e.d_tw);
+    if ( ctx->d_cs )
+	(void)hipFree(ctx->d_cs);
+    delete ctx;
+}
+
+extern "C" const char *mifsk_ctx_device_name( const mifsk_ctx *ctx )
+{
+    return ctx ? ctx->name : "";
+}
+
+// exp(-2 pi i b n / N): the angle is reduced exactly in integers first
+static inline void twiddle( unsigned b, unsigned n, unsigned fftsize, double w[2] )
+{
+    const unsigned long long k = ( (unsigned long long)b * n ) % fftsize;
+    const double ang = 2.0 * M_PI * (double)k / (double)fftsize;
+    w[0] = std::cos(ang);
+    w[1] = -std::sin(ang);
+}
+
+static int get_twiddles( mifsk_ctx *ctx, const TwKey &key, const double **d_out )
+{
+    std::lock_guard<std::mutex> g(ctx->lock);
+    for ( const TwEntry &e : ctx->tables )
+	if ( e.key == key ) {
+	    *d_out = e.d_tw;
+	    return 0;
+	}
+    const size_t n = key.bit_nsamples ? key.bit_nsamples : 1;
+    std::vector<double> h(4 * n);
+    for ( unsigned i = 0; i < key.bit_nsamples; i++ ) {
+	twiddle(key.b_mark, i, key.fftsize, &h[4 * (size_t)i]);
+	twiddle(key.b_space, i, key.fftsize, &h[4 * (size_t)i + 2]);
+    }
+    double *d = nullptr;
+    HIP_OK(hipMalloc(&d, h.size() * sizeof(double)));
+    HIP_OK(hipMemcpy(d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+    ctx->tables.push_back(TwEntry{key, d});
+    *d_out = d;
+    return 0;
+}
+
+static int check_cfg( const mifsk_rx_config *cfg )
+{
+    if ( !cfg || cfg->expect_n_bits == 0 || cfg->expect_n_bits > MIFSK_MAX_FRAME_BITS
+	    || cfg->bit_nsamples == 0 || cfg->fftsize < 2 )
+	return -EINVAL;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// batch entry points
+// ---------------------------------------------------------------------------
+
+extern "C" int mifsk_find_frame_batch( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
+	const float *d_samples, const mifsk_search *d_problems,
+	mifsk_search_result *d_results, int nproblems, void *stream )
+{
+    if ( !ctx || check_cfg(cfg) || ( nproblems > 0 && ( !d_samples || !d_problems || !d_results ) ) )
+	return -EINVAL;
+    HIP_OK(hipSetDevice(ctx->device));
+    const double *d_tw = nullptr;
+    int rc = get_twiddles(ctx, TwKey{(unsigned)cfg->fftsize, cfg->b_mark, cfg->b_space,
+				     cfg->bit_nsamples}, &d_tw);
+    if ( rc )
+	return rc;
+    DevCfg d;
+    mifsk::fill_devcfg(d, *cfg);
+    return mifsk::launch_find_frame_batch(d, d_tw, d_samples, d_problems, d_results,
+					  nproblems, stream);
+}
+
+extern "C" int mifsk_demod_batch( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
+	const mifsk_demod_io *io, void *stream )
+{
+    if ( !ctx || !io || check_cfg(cfg) )
+	return -EINVAL;
+    if ( cfg->auto_carrier_threshold > 0.0f )
+	return -ENOSYS;
+    if ( io->nstreams < 0 || ( io->nstreams > 0 && !io->d_samples ) )
+	return -EINVAL;
+    if ( io->stream_stride % 4 != 0 || ( (uintptr_t)io->d_samples & 15u ) )
+	return -EINVAL;		// rows must be 16-byte aligned (coalesced float4 staging)
+    if ( ( io->d_bytes || io->d_bits || io->d_frames ) && io->frames_cap == 0 )
+	return -EINVAL;
+    HIP_OK(hipSetDevice(ctx->device));
+    const double *d_tw = nullptr;
+    int rc = get_twiddles(ctx, TwKey{(unsigned)cfg->fftsize, cfg->b_mark, cfg->b_space,
+				     cfg->bit_nsamples}, &d_tw);
+    if ( rc )
+	return rc;
+    DevCfg d;
+    mifsk::fill_devcfg(d, *cfg);
+    return mifsk::launch_demod_batch(d, d_tw, *io, stream);
+}
+
+namespace {
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    ~DevBuf() { if ( p ) (void)hipFree(p); }
+    int alloc( size_t n ) { return hipMalloc(&p, ( n ? n : 1 ) * sizeof(T)) == hipSuccess ? 0 : -ENOMEM; }
+};
+
+} // namespace
+
+extern "C" int mifsk_demod_batch_host( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
+	const mifsk_demod_io *hio )
+{
+    if ( !ctx || !hio || check_cfg(cfg) || hio->nstreams < 0 )
+	return -EINVAL;
+    HIP_OK(hipSetDevice(ctx->device));
+    const size_t ns = (size_t)hio->nstreams;
+    if ( ns == 0 )
+	return 0;
+    // device rows: stride rounded up to 4 floats
+    uint32_t maxn = hio->nsamples;
+    if ( hio->d_nsamples ) {
+	maxn = 0;
+	for ( size_t i = 0; i < ns; i++ )
+	    maxn = hio->d_nsamples[i] > maxn ? hio->d_nsamples[i] : maxn;
+    }
+    const size_t dstride = ( (size_t)maxn + 3 ) & ~(size_t)3;
+    DevBuf<float> d_x;
+    DevBuf<uint32_t> d_n, d_nbytes, d_nframes, d_neps, d_status;
+    DevBuf<uint8_t> d_bytes;
+    DevBuf<uint64_t> d_bits;
+    DevBuf<mifsk_frame> d_frames;
+    DevBuf<mifsk_episode> d_eps;
+    if ( d_x.alloc(ns * dstride ? ns * dstride : 4) )
+	return -ENOMEM;
+    if ( dstride ) {
+	HIP_OK(hipMemcpy2D(d_x.p, dstride * sizeof(float), hio->d_samples,
+			   hio->stream_stride * sizeof(float),
+			   ( hio->stream_stride < dstride ? hio->stream_stride : dstride ) * sizeof(float),
+			   ns, hipMemcpyHostToDevice));
+    }
+    mifsk_demod_io io = *hio;
+    io.d_samples = d_x.p;
+    io.stream_stride = dstride;
+    if ( hio->d_nsamples ) {
+	if ( d_n.alloc(ns) ) return -ENOMEM;
+	HIP_OK(hipMemcpy(d_n.p, hio->d_nsamples, ns * sizeof(uint32_t), hipMemcpyHostToDevice));
+	io.d_nsamples = d_n.p;
+    }
+    const size_t fc = hio->frames_cap, ec = hio->episodes_cap;
+    if ( hio->d_bytes )    { if ( d_bytes.alloc(ns * fc) ) return -ENOMEM;  io.d_bytes = d_bytes.p; }
+    if ( hio->d_bits )     { if ( d_bits.alloc(ns * fc) ) return -ENOMEM;   io.d_bits = d_bits.p; }
+    if ( hio->d_frames )   { if ( d_frames.alloc(ns * fc) ) return -ENOMEM; io.d_frames = d_frames.p; }
+    if ( hio->d_episodes ) { if ( d_eps.alloc(ns * ec) ) return -ENOMEM;    io.d_episodes = d_eps.p; }
+    if ( hio->d_nbytes )   { if ( d_nbytes.alloc(ns) ) return -ENOMEM;      io.d_nbytes = d_nbytes.p; }
+    if ( hio->d_nframes )  { if ( d_nframes.alloc(ns) ) return -ENOMEM;     io.d_nframes = d_nframes.p; }
+    if ( hio->d_nepisodes ){ if ( d_neps.alloc(ns) ) return -ENOMEM;        io.d_nepisodes = d_neps.p; }
+    if ( hio->d_status )   { if ( d_status.alloc(ns) ) return -ENOMEM;      io.d_status = d_status.p; }
+
+    int rc = mifsk_demod_batch(ctx, cfg, &io, nullptr);
+    if ( rc )
+	return rc;
+    HIP_OK(hipDeviceSynchronize());
+    if ( hio->d_bytes )    HIP_OK(hipMemcpy(hio->d_bytes, d_bytes.p, ns * fc, hipMemcpyDeviceToHost));
+    if ( hio->d_bits )     HIP_OK(hipMemcpy(hio->d_bits, d_bits.p, ns * fc * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if ( hio->d_frames )   HIP_OK(hipMemcpy(hio->d_frames, d_frames.p, ns * fc * sizeof(mifsk_frame), hipMemcpyDeviceToHost));
+    if ( hio->d_episodes ) HIP_OK(hipMemcpy(hio->d_episodes, d_eps.p, ns * ec * sizeof(mifsk_episode), hipMemcpyDeviceToHost));
+    if ( hio->d_nbytes )   HIP_OK(hipMemcpy(hio->d_nbytes, d_nbytes.p, ns * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if ( hio->d_nframes )  HIP_OK(hipMemcpy(hio->d_nframes, d_nframes.p, ns * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if ( hio->d_nepisodes )HIP_OK(hipMemcpy(hio->d_nepisodes, d_neps.p, ns * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if ( hio->d_status )   HIP_OK(hipMemcpy(hio->d_status, d_status.p, ns * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// the reference's five-function API (include/fsk.h) over the same kernels
+// ---------------------------------------------------------------------------
+
+namespace {
+
+struct LegacyPlan {
+    mifsk_ctx		*ctx;
+    float		*d_samples;	size_t cap_samples;
+    mifsk_search	*d_problem;
+    mifsk_search_result	*d_result;
+    float		*d_mags;	size_t cap_mags;
+};
+
+int legacy_reserve( LegacyPlan *lp, size_t nsamples )
+{
+    if ( nsamples <= lp->cap_samples )
+	return 0;
+    if ( lp->d_samples )
+	(void)hipFree(lp->d_samples);
+    lp->d_samples = nullptr;
+    lp->cap_samples = 0;
+    const size_t cap = ( nsamples + 4095 ) & ~(size_t)4095;
+    if ( hipMalloc(&lp->d_samples, cap * sizeof(float)) != hipSuccess )
+	return -ENOMEM;
+    lp->cap_samples = cap;
+    return 0;
+}
+
+} // namespace
+
+extern "C" fsk_plan *fsk_plan_new( float sample_rate, float f_mark, float f_space,
+	float filter_bw )
+{
+    fsk_plan *p = (fsk_plan *)std::calloc(1, sizeof(fsk_plan));
+    if ( !p ) {
+	errno = ENOMEM;
+	return nullptr;
+    }
+    p->sample_rate = sample_rate;
+    p->f_mark = f_mark;
+    p->f_space = f_space;
+    p->band_width = filter_bw;
+    const float half = p->band_width / 2.0f;			// fsk.c:52-57
+    p->fftsize = (int)( (sample_rate + half) / p->band_width );
+    p->nbands = (unsigned)( p->fftsize / 2 + 1 );
+    p->b_mark = (unsigned)( (f_mark + half) / p->band_width );
+    p->b_space = (unsigned)( (f_space + half) / p->band_width );
+    if ( p->b_mark >= p->nbands || p->b_space >= p->nbands ) {	// fsk.c:58-64
+	fprintf(stderr, "b_mark=%u or b_space=%u is invalid (nbands=%u)\n",
+		p->b_mark, p->b_space, p->nbands);
+	std::free(p);
+	errno = EINVAL;
+	return nullptr;
+    }
+    LegacyPlan *lp = new (std::nothrow) LegacyPlan();
+    if ( !lp ) {
+	std::free(p);
+	errno = ENOMEM;
+	return nullptr;
+    }
+    std::memset(lp, 0, sizeof(*lp));
+    int rc = mifsk_ctx_create(&lp->ctx, -1);
+    if ( rc == 0 && ( hipMalloc(&lp->d_problem, sizeof(mifsk_search)) != hipSuccess
+		   || hipMalloc(&lp->d_result, sizeof(mifsk_search_result)) != hipSuccess ) )
+	rc = -ENOMEM;
+    if ( rc ) {
+	if ( lp->ctx ) mifsk_ctx_destroy(lp->ctx);
+	delete lp;
+	std::free(p);
+	errno = -rc;
+	return nullptr;
+    }
+    p->fftplan = lp;
+    p->fftin = nullptr;
+    p->fftout = nullptr;
+    return p;
+}
+
+extern "C" void fsk_plan_destroy( fsk_plan *p )
+{
+    if ( !p )
+	return;
+    LegacyPlan *lp = (LegacyPlan *)p->fftplan;
+    if ( lp ) {
+	if ( lp->d_samples ) (void)hipFree(lp->d_samples);
+	if ( lp->d_problem ) (void)hipFree(lp->d_problem);
+	if ( lp->d_result ) (void)hipFree(lp->d_result);
+	if ( lp->d_mags ) (void)hipFree(lp->d_mags);
+	mifsk_ctx_destroy(lp->ctx);
+	delete lp;
+    }
+    std::free(p);
+}
+
+extern "C" float fsk_find_frame( fsk_plan *p, float *samples, unsigned int frame_nsamples,
+	unsigned int try_first_sample, unsigned int try_max_nsamples,
+	unsigned int try_step_nsamples, float try_confidence_search_limit,
+	const char *expect_bits_string, unsigned long long *bits_outp,
+	float *ampl_outp, unsigned int *frame_start_outp )
+{
+    *bits_outp = 0;
+    *ampl_outp = 0.0f;
+    *frame_start_outp = 0;
+    LegacyPlan *lp = p ? (LegacyPlan *)p->fftplan : nullptr;
+    const size_t n_bits = expect_bits_string ? std::strlen(expect_bits_string) : 0;
+    if ( !lp || n_bits == 0 || n_bits > MIFSK_MAX_FRAME_BITS	// assert in fsk.c:463
+	    || (int)try_first_sample >= (int)try_max_nsamples || try_step_nsamples == 0 )
+	return 0.0f;
+
+    // the slice of the configuration that fsk_find_frame itself derives
+    // (fsk.c:465,183,204); everything else in DevCfg is unused by this kernel
+    mifsk_rx_config c;
+    std::memset(&c, 0, sizeof(c));
+    c.expect_n_bits = (unsigned)n_bits;
+    const float spb = (float)frame_nsamples / (float)(int)n_bits;
+    c.find_samples_per_bit = spb;
+    c.bit_nsamples = (unsigned)( spb + 0.5f );
+    if ( c.bit_nsamples == 0 )
+	return 0.0f;
+    for ( unsigned k = 0; k < n_bits; k++ ) {
+	c.bit_offset[k] = (unsigned)( spb * (float)(int)k + 0.5f );
+	c.expect_data[k] = expect_bits_string[k];
+	c.expect_sync[k] = expect_bits_string[k];
+    }
+    c.fftsize = p->fftsize;
+    c.b_mark = p->b_mark;
+    c.b_space = p->b_space;
+
+    const size_t reach = (size_t)try_max_nsamples - 1 + c.bit_offset[n_bits - 1] + c.bit_nsamples;
+    if ( hipSetDevice(lp->ctx->device) != hipSuccess || legacy_reserve(lp, reach) )
+	return 0.0f;
+    mifsk_search pr;
+    pr.sample_offset = 0;
+    pr.navail = (uint32_t)reach;
+    pr.try_first = try_first_sample;
+    pr.try_max = try_max_nsamples;
+    pr.try_step = try_step_nsamples;
+    pr.search_limit = try_confidence_search_limit;
+    pr.use_sync_string = 0;
+    mifsk_search_result res;
+    if ( hipMemcpy(lp->d_samples, samples, reach * sizeof(float), hipMemcpyHostToDevice) != hipSuccess
+	    || hipMemcpy(lp->d_problem, &pr, sizeof(pr), hipMemcpyHostToDevice) != hipSuccess )
+	return 0.0f;
+    if ( mifsk_find_frame_batch(lp->ctx, &c, lp->d_samples, lp->d_problem, lp->d_result, 1, nullptr) )
+	return 0.0f;
+    if ( hipMemcpy(&res, lp->d_result, sizeof(res), hipMemcpyDeviceToHost) != hipSuccess )
+	return 0.0f;
+    *bits_outp = res.bits;
+    *ampl_outp = res.amplitude;
+    *frame_start_outp = res.frame_start;
+    return res.confidence;
+}
+
+extern "C" int fsk_detect_carrier( fsk_plan *p, float *samples, unsigned int nsamples,
+	float min_mag_threshold )
+{
+    LegacyPlan *lp = p ? (LegacyPlan *)p->fftplan : nullptr;
+    if ( !lp || nsamples == 0 || nsamples > (unsigned)p->fftsize )	// assert in fsk.c:547
+	return -1;
+    mifsk_ctx *ctx = lp->ctx;
+    if ( hipSetDevice(ctx->device) != hipSuccess )
+	return -1;
+    const unsigned N = (unsigned)p->fftsize;
+    if ( ctx->cs_fftsize != N ) {
+	std::vector<double> h(2 * (size_t)N);
+	for ( unsigned k = 0; k < N; k++ ) {
+	    const double ang = 2.0 * M_PI * (double)k / (double)N;
+	    h[2 * (size_t)k] = std::cos(ang);
+	    h[2 * (size_t)k + 1] = -std::sin(ang);
+	}
+	if ( ctx->d_cs ) (void)hipFree(ctx->d_cs);
+	ctx->d_cs = nullptr;
+	ctx->cs_fftsize = 0;
+	if ( hipMalloc(&ctx->d_cs, h.size() * sizeof(double)) != hipSuccess
+		|| hipMemcpy(ctx->d_cs, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess )
+	    return -1;
+	ctx->cs_fftsize = N;
+    }
+    if ( legacy_reserve(lp, nsamples) )
+	return -1;
+    if ( lp->cap_mags < p->nbands ) {
+	if ( lp->d_mags ) (void)hipFree(lp->d_mags);
+	lp->d_mags = nullptr;
+	lp->cap_mags = 0;
+	if ( hipMalloc(&lp->d_mags, p->nbands * sizeof(float)) != hipSuccess )
+	    return -1;
+	lp->cap_mags = p->nbands;
+    }
+    if ( hipMemcpy(lp->d_samples, samples, nsamples * sizeof(float), hipMemcpyHostToDevice) != hipSuccess )
+	return -1;
+    if ( mifsk::launch_detect_carrier(lp->d_samples, nsamples, ctx->d_cs, N, p->nbands,
+				      lp->d_mags, nullptr) )
+	return -1;
+    std::vector<float> mags(p->nbands);
+    if ( hipMemcpy(mags.data(), lp->d_mags, p->nbands * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess )
+	return -1;
+    // peak pick over the device-computed magnitudes (fsk.c:554-580)
+    float max_mag = 0.0f;
+    int max_band = -1;
+    for ( unsigned i = 1; i < p->nbands; i++ ) {
+	const float mag = mags[i];
+	if ( mag < min_mag_threshold )
+	    continue;
+	if ( max_mag < mag ) {
+	    max_mag = mag;
+	    max_band = (int)i;
+	}
+    }
+    return max_band;
+}
+
+extern "C" void fsk_set_tones_by_bandshift( fsk_plan *p, unsigned int b_mark, int b_shift )
+{
+    if ( !p || b_shift == 0 || b_mark >= p->nbands )		// asserts in fsk.c:587-592
+	return;
+    const int b_space = (int)b_mark + b_shift;
+    if ( b_space < 0 || b_space >= (int)p->nbands )
+	return;
+    p->b_mark = b_mark;
+    p->b_space = (unsigned)b_space;
+    p->f_mark = b_mark * p->band_width;
+    p->f_space = b_space * p->band_width;
+}

@@ -1,0 +1,54 @@
+// mifsk_device.h -- types shared by the host glue and the HIP kernels.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+
+#include "mifsk.h"
+
+namespace mifsk {
+
+// Everything a kernel needs, as one POD passed by value in the kernarg
+// segment (so it lands in SGPRs / the scalar cache, uniform for the launch).
+struct DevCfg {
+    uint32_t	n_bits;			// expect_n_bits (<= 64)
+    uint32_t	bit_nsamples;		// samples per bit window   (fsk.c:183)
+    uint32_t	last_reach;		// bit_offset[n_bits-1] + bit_nsamples
+    float	magscalar;		// 2.0f / bit_nsamples      (fsk.c:132)
+    uint32_t	frame_nsamples;
+    uint32_t	expect_nsamples;
+    uint32_t	overscan;
+    uint32_t	try_first[2], try_max[2], try_step[2], try_step_fine[2];
+    float	conf_threshold;
+    float	search_limit;
+    uint32_t	n_data_bits;
+    uint32_t	nstartbits;
+    uint32_t	has_stopbits;
+    uint32_t	msb_first;
+    uint32_t	do_rx_sync;
+    uint32_t	rx_one;
+    uint64_t	sync_byte;
+    uint32_t	skew;			// LDS slab row padding (see mifsk_kernels.hip)
+    uint32_t	pad0;
+    uint32_t	bit_offset[MIFSK_MAX_FRAME_BITS];	// fsk.c:204
+    uint8_t	expect[2][MIFSK_MAX_FRAME_BITS];	// [0]=data [1]=sync; 0,1 or 2 ('d')
+};
+
+// twiddles: tw[4*n + {0,1,2,3}] = cos_mark, -sin_mark, cos_space, -sin_space
+// of angle 2*pi*((b*n) mod fftsize)/fftsize, in double.
+
+void fill_devcfg( DevCfg &d, const mifsk_rx_config &c );
+
+// launchers (mifsk_kernels.hip); `stream` is a hipStream_t
+int launch_find_frame_batch( const DevCfg &cfg, const double *d_tw,
+	const float *d_samples, const mifsk_search *d_problems,
+	mifsk_search_result *d_results, int nproblems, void *stream );
+
+int launch_demod_batch( const DevCfg &cfg, const double *d_tw,
+	const mifsk_demod_io &io, void *stream );
+
+int launch_detect_carrier( const float *d_samples, unsigned nsamples,
+	const double *d_cs /* [fftsize][2] */, unsigned fftsize, unsigned nbands,
+	float *d_mags /* [nbands] */, void *stream );
+
+} // namespace mifsk

@@ -1,0 +1,87 @@
+"""Host logic (no GPU): the product's derived receive configuration
+(csrc/mifsk_config.cpp) against SURVEY Appendix A (the reference's own
+arithmetic) and against the oracle's independent derivation."""
+import ctypes as C
+
+import pytest
+
+import _oracle as O
+import minimodem_amd as M
+from minimodem_amd import _lib
+
+# mode kwargs -> (fftsize, b_mark, b_space, bit_nsamples, expect_data, expect_nsamples,
+#                 frame_nsamples, overscan, samplebuf, (nocarrier max, step),
+#                 (carrier first, max, step, fine))         -- SURVEY.md Appendix A
+APPENDIX_A = [
+    (dict(baudmode="1200"), 240, 6, 11, 40, "10dddddddd1", 440, 400, 20, 4000, (60, 20), (20, 50, 16, 6)),
+    (dict(baudmode="300"), 960, 25, 21, 160, "10dddddddd1", 1760, 1600, 80, 4000, (240, 80), (80, 200, 66, 25)),
+    (dict(baudmode="rtty"), 4800, 159, 142, 1056, "10ddddd1", 8448, 7393, 528, 19026, (1584, 528), (528, 1320, 440, 165)),
+    (dict(baudmode="tdd"), 4800, 140, 180, 1056, "10ddddd1", 8448, 8449, 528, 19026, (1584, 528), (528, 1320, 440, 165)),
+    (dict(baudmode="12000"), 240, 33, 83, 4, "10dddddddd1", 44, 40, 2, 4000, (6, 2), (2, 5, 1, 1)),
+    (dict(baudmode="same"), 92, 4, 3, 92, "dddddddd", 737, 737, 46, 4000, (138, 46), (46, 115, 38, 14)),
+    (dict(baudmode="1200", sample_rate=24000, mark_f=1200, space_f=2400), 120, 6, 12, 20,
+     "10dddddddd1", 220, 200, 10, 2000, (30, 10), (10, 25, 8, 3)),
+    (dict(baudmode="0.5"), 96000, 3170, 2830, 96000, "10dddddddd1", 1056000, 960000, 48000,
+     2304000, (144000, 48000), (48000, 120000, 40000, 15000)),
+    (dict(baudmode="uic-ground"), 240, 7, 9, 80, "11110010" + "d" * 39, 3760, 3760, 40, 8000,
+     (120, 40), (40, 100, 33, 12)),
+]
+
+
+@pytest.mark.parametrize("row", APPENDIX_A, ids=[r[0]["baudmode"] + str(r[0].get("sample_rate", "")) for r in APPENDIX_A])
+def test_appendix_a(row):
+    kw, fftsize, bm, bs, bitn, expect, en, fn, osc, buf, nc, ca = row
+    for cfg in (M.rx_config(**kw), O.oracle_config(**kw)):
+        assert cfg.fftsize == fftsize
+        assert (cfg.b_mark, cfg.b_space) == (bm, bs)
+        assert cfg.bit_nsamples == bitn
+        assert cfg.expect_data.decode() == expect
+        assert cfg.expect_nsamples == en
+        assert cfg.frame_nsamples == fn
+        assert cfg.nsamples_overscan == osc
+        assert cfg.samplebuf_size == buf
+        assert (cfg.try_max[0], cfg.try_step[0]) == nc
+        assert (cfg.try_first[1], cfg.try_max[1], cfg.try_step[1], cfg.try_step_fine[1]) == ca
+
+
+MODES = [
+    dict(baudmode="1200"), dict(baudmode="300"), dict(baudmode="rtty"), dict(baudmode="tdd"),
+    dict(baudmode="same"), dict(baudmode="callerid"), dict(baudmode="uic-train"),
+    dict(baudmode="uic-ground"), dict(baudmode="V.21"), dict(baudmode="12000"),
+    dict(baudmode="0.5"), dict(baudmode="110"), dict(baudmode="1000", sample_rate=44100),
+    dict(baudmode="1200", n_data_bits=7), dict(baudmode="1200", inverted_freqs=1),
+    dict(baudmode="300", nstopbits=2.0), dict(baudmode="1200", sync_byte=0x7E),
+    dict(baudmode="1200", msb_first=1, invert_start_stop=1),
+    dict(baudmode="1200", binary_raw_nbits=16), dict(baudmode="rtty", n_data_bits=8),
+    dict(baudmode="1200", confidence_threshold=3.0, search_limit=1.0),
+    dict(baudmode="2400", mark_f=2400, space_f=1200, band_width=100),
+    dict(baudmode="1200", sample_rate=8000), dict(baudmode="1200", rx_one=1),
+]
+
+
+@pytest.mark.parametrize("kw", MODES, ids=[str(i) for i in range(len(MODES))])
+def test_product_config_equals_oracle_config(kw):
+    a = M.rx_config(**kw).as_dict()
+    b = O.oracle_config(**kw).as_dict()
+    assert a == b
+
+
+def test_invalid_modes_rejected():
+    for kw in (dict(baudmode="bogus"), dict(baudmode="1200", mark_f=30000.0),
+               dict(baudmode="1200", binary_raw_nbits=70)):
+        with pytest.raises(ValueError):
+            M.rx_config(**kw)
+        with pytest.raises(ValueError):
+            O.oracle_config(**kw)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    for name in _lib.EXPORTS:
+        assert hasattr(lib, name), name
+    assert lib.mifsk_abi_version() == 1
+
+
+def test_struct_layouts_match_between_bindings():
+    assert C.sizeof(_lib.RxConfig) == C.sizeof(O.RxConfig)
+    assert C.sizeof(_lib.ModemArgs) == C.sizeof(O.ModemArgs)
