@@ -220,7 +220,23 @@ typedef struct mifsk_demod_io {
     uint32_t		*d_nepisodes;	/* [nstreams]                        */
     size_t		episodes_cap;
     uint32_t		*d_status;	/* [nstreams] MIFSK_STREAM_* or NULL */
+    uint64_t		*d_counters;	/* [nstreams][MIFSK_NCOUNTERS] work
+					   counters (MIFSK_CNT_*) or NULL    */
 } mifsk_demod_io;
+
+/* per-stream work counters (diagnostics; cycle counts are s_memtime ticks) */
+#define MIFSK_NCOUNTERS		16
+#define MIFSK_CNT_ITERATIONS	0	/* passes through the general loop body  */
+#define MIFSK_CNT_BATCHES	1	/* candidate batches evaluated           */
+#define MIFSK_CNT_STAGES	2	/* LDS slab (re)loads                    */
+#define MIFSK_CNT_BULK_FRAMES	3	/* frames accepted from the run-ahead    */
+#define MIFSK_CNT_REFINES	4	/* fine rescans                          */
+#define MIFSK_CNT_CACHE_HITS	5	/* searches answered from the cache      */
+#define MIFSK_CNT_POSITIONS	6	/* candidate positions evaluated         */
+#define MIFSK_CNT_CYC_TOTAL	8
+#define MIFSK_CNT_CYC_PARALLEL	9	/* stage + correlate, incl. barriers     */
+#define MIFSK_CNT_CYC_CONFIDENCE 11
+#define MIFSK_CNT_CYC_BULK	12
 
 int mifsk_demod_batch( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
 	const mifsk_demod_io *io, void *stream );

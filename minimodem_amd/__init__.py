@@ -34,6 +34,10 @@ SEARCH_DTYPE = np.dtype([("sample_offset", "<u8"), ("navail", "<u4"), ("try_firs
 RESULT_DTYPE = np.dtype([("bits", "<u8"), ("confidence", "<f4"), ("amplitude", "<f4"),
                          ("frame_start", "<u4"), ("n_positions", "<u4")])
 assert SEARCH_DTYPE.itemsize == 32 and RESULT_DTYPE.itemsize == 24
+NCOUNTERS = 16
+COUNTER_NAMES = {0: "iterations", 1: "batches", 2: "stages", 3: "bulk_frames", 4: "refines",
+                 5: "cache_hits", 6: "positions", 8: "cyc_total", 9: "cyc_parallel",
+                 11: "cyc_confidence", 12: "cyc_bulk"}
 
 
 def build(force=False):
@@ -140,6 +144,8 @@ def demod_batch(ctx, cfg, samples, nsamples=None, want=("bytes", "episodes"),
         if "frames" in want:
             out["frames"] = torch.zeros((nstreams, frames_cap, FRAME_DTYPE.itemsize),
                                         dtype=torch.uint8, device=dev)
+        if "counters" in want:
+            out["counters"] = torch.zeros((nstreams, NCOUNTERS), dtype=torch.int64, device=dev)
         if "episodes" in want:
             out["episodes"] = torch.zeros((nstreams, episodes_cap, EPISODE_DTYPE.itemsize),
                                           dtype=torch.uint8, device=dev)
@@ -165,6 +171,7 @@ def demod_batch(ctx, cfg, samples, nsamples=None, want=("bytes", "episodes"),
     io.d_nepisodes = ptr("nepisodes")
     io.episodes_cap = episodes_cap
     io.d_status = ptr("status")
+    io.d_counters = ptr("counters")
     rc = lib.mifsk_demod_batch(ctx.handle, C.byref(cfg), C.byref(io), _stream_ptr(torch, stream))
     if rc != 0:
         raise RuntimeError("mifsk_demod_batch failed: %d" % rc)

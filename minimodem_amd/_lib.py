@@ -129,6 +129,7 @@ class DemodIO(C.Structure):
         ("d_nepisodes", C.c_void_p),
         ("episodes_cap", C.c_size_t),
         ("d_status", C.c_void_p),
+        ("d_counters", C.c_void_p),
     ]
 
 

@@ -52,6 +52,9 @@ void fill_devcfg( DevCfg &d, const mifsk_rx_config &c )
     d.sync_byte = c.sync_byte;
     // odd row pitch => lanes one bit apart never share an LDS bank
     d.skew = ( c.bit_nsamples & 1u ) ? 0u : 1u;
+    d.div_magic = c.bit_nsamples > 1 ? (uint32_t)( 0x100000000ULL / c.bit_nsamples ) : 0xFFFFFFFFu;
+    // minimodem.c:1407 with frame_start == try_first (carrier)
+    d.lock_advance = c.try_first[1] + c.frame_nsamples - c.nsamples_overscan;
     for ( unsigned k = 0; k < c.expect_n_bits; k++ ) {
 	d.bit_offset[k] = c.bit_offset[k];
 	for ( int s = 0; s < 2; s++ ) {
@@ -167,8 +170,10 @@ static int get_twiddles( mifsk_ctx *ctx, const TwKey &key, const double **d_out 
 	    *d_out = e.d_tw;
 	    return 0;
 	}
-    const size_t n = key.bit_nsamples ? key.bit_nsamples : 1;
-    std::vector<double> h(4 * n);
+    // zero-padded to a multiple of 8 samples: the correlator consumes the
+    // table in chunks of 8 and fma(x, 0, acc) leaves acc unchanged
+    const size_t n = ( (size_t)key.bit_nsamples + 7 ) & ~(size_t)7;
+    std::vector<double> h(4 * ( n ? n : 8 ), 0.0);
     for ( unsigned i = 0; i < key.bit_nsamples; i++ ) {
 	twiddle(key.b_mark, i, key.fftsize, &h[4 * (size_t)i]);
 	twiddle(key.b_space, i, key.fftsize, &h[4 * (size_t)i + 2]);
@@ -269,6 +274,7 @@ extern "C" int mifsk_demod_batch_host( mifsk_ctx *ctx, const mifsk_rx_config *cf
     DevBuf<uint64_t> d_bits;
     DevBuf<mifsk_frame> d_frames;
     DevBuf<mifsk_episode> d_eps;
+    DevBuf<uint64_t> d_cnt;
     if ( d_x.alloc(ns * dstride ? ns * dstride : 4) )
 	return -ENOMEM;
     if ( dstride ) {
@@ -294,6 +300,7 @@ extern "C" int mifsk_demod_batch_host( mifsk_ctx *ctx, const mifsk_rx_config *cf
     if ( hio->d_nframes )  { if ( d_nframes.alloc(ns) ) return -ENOMEM;     io.d_nframes = d_nframes.p; }
     if ( hio->d_nepisodes ){ if ( d_neps.alloc(ns) ) return -ENOMEM;        io.d_nepisodes = d_neps.p; }
     if ( hio->d_status )   { if ( d_status.alloc(ns) ) return -ENOMEM;      io.d_status = d_status.p; }
+    if ( hio->d_counters ) { if ( d_cnt.alloc(ns * MIFSK_NCOUNTERS) ) return -ENOMEM; io.d_counters = d_cnt.p; }
 
     int rc = mifsk_demod_batch(ctx, cfg, &io, nullptr);
     if ( rc )
@@ -307,6 +314,7 @@ extern "C" int mifsk_demod_batch_host( mifsk_ctx *ctx, const mifsk_rx_config *cf
     if ( hio->d_nframes )  HIP_OK(hipMemcpy(hio->d_nframes, d_nframes.p, ns * sizeof(uint32_t), hipMemcpyDeviceToHost));
     if ( hio->d_nepisodes )HIP_OK(hipMemcpy(hio->d_nepisodes, d_neps.p, ns * sizeof(uint32_t), hipMemcpyDeviceToHost));
     if ( hio->d_status )   HIP_OK(hipMemcpy(hio->d_status, d_status.p, ns * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if ( hio->d_counters ) HIP_OK(hipMemcpy(hio->d_counters, d_cnt.p, ns * MIFSK_NCOUNTERS * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -77,6 +77,7 @@ frame_confidence( const float2 *mags, const uint8_t *expect, uint32_t n_bits )
     float mark_sig = 0.0f, space_sig = 0.0f;
     uint32_t n_mark = 0, n_space = 0;
     bool mismatch = false;
+#pragma unroll 4
     for ( uint32_t k = 0; k < n_bits; k++ ) {
 	const float2 m = mags[k];
 	const bool one = m.x > m.y;			// fsk.c:161 (strict)
@@ -108,6 +109,7 @@ frame_confidence( const float2 *mags, const uint8_t *expect, uint32_t n_bits )
 	space_sig /= (float)n_space;
 
     float divergence = 0.0f;				// fsk.c:305-313
+#pragma unroll 4
     for ( uint32_t k = 0; k < n_bits; k++ ) {
 	const float2 m = mags[k];
 	const bool one = m.x > m.y;
@@ -250,6 +252,13 @@ void find_frame_kernel( DevCfg cfg, const double *__restrict__ tw,
 
 // ---------------------------------------------------------------------------
 // kernel 2: the receive loop, one workgroup per stream
+//
+// Wave 0 is the MASTER: it owns the reference's loop state and runs the serial
+// decision logic.  Waves 1..3 are WORKERS: they only ever execute the two
+// data-parallel steps (stage the LDS slab, correlate bit windows), driven by a
+// command block in LDS.  Every wave meets at the same sequence of s_barriers
+// (command published -> [staged] -> correlated), so the serial logic costs one
+// wave's issue slots instead of four.
 // ---------------------------------------------------------------------------
 
 struct StreamLds {
@@ -258,9 +267,14 @@ struct StreamLds {
     float	c_conf[P_CAP];
     float	c_ampl[P_CAP];
     uint32_t	c_pos[P_CAP];
-    uint32_t	c_n;
-    uint32_t	c_kind;
-    uint32_t	pad[2];
+    uint32_t	c_n;		// valid cache entries
+    uint32_t	c_kind;		// expect string they were evaluated with
+    uint32_t	c_q;		// entries [c_q, c_n) are run-ahead frames, lock_advance apart
+    uint32_t	cmd_op;		// 0: exit, 1: evaluate c_pos[0..cmd_nq)
+    uint32_t	cmd_nq;
+    uint32_t	cmd_stage;	// 1: restage the slab at cmd_row_org first
+    uint32_t	cmd_row_org;	// absolute sample index of slab row 0
+    uint32_t	pad;
     float	slab[1];	// really slab_floats long (dynamic LDS)
 };
 
@@ -269,11 +283,192 @@ struct ScanResult {
     float	ampl;
     uint64_t	bits;
     uint32_t	start;
-    uint32_t	computed;	// 1 when a batch was evaluated (cache was rewritten)
 };
 
+constexpr int XCH = 8;		// samples per register chunk in the correlator
+constexpr int STAGE_VEC = 10;	// float4 per thread per staging round
+
+// rel / bit_nsamples without a hardware divide: magic = floor(2^32 / B)
+// under-estimates the quotient by at most one
+__device__ __forceinline__ void divmod_bit( const DevCfg &cfg, uint32_t rel, uint32_t &q, uint32_t &r )
+{
+    q = __umulhi(rel, cfg.div_magic);
+    r = rel - q * cfg.bit_nsamples;
+    if ( r >= cfg.bit_nsamples ) {
+	q++;
+	r -= cfg.bit_nsamples;
+    }
+}
+
+// Stage samples [row_org, row_org + slab_cap) of the stream into the slab (all
+// threads).  Global reads are 16-byte aligned float4 (coalesced, 1 KiB per wave
+// instruction); the LDS word of sample a is rel + (rel / B) * skew with
+// rel = a - row_org: rows of one bit length with `skew` pad words in between,
+// so lanes whose windows start a whole number of bits apart read different
+// banks.  Samples at or beyond N are zero.
+__device__ void par_stage( const DevCfg &cfg, StreamLds *lds, const float *__restrict__ x,
+	uint32_t N, uint32_t slab_cap, uint32_t row_org )
+{
+    const uint32_t org4 = row_org & ~3u;
+    const uint32_t head = row_org - org4;		// 0..3 samples before row 0: dropped
+    float *slab = lds->slab;
+    const uint32_t nvec = ( slab_cap + head + 3 ) >> 2;
+    const uint32_t B = cfg.bit_nsamples, skew = cfg.skew;
+    for ( uint32_t v0 = 0; v0 < nvec; v0 += BLOCK * STAGE_VEC ) {
+	float4 buf[STAGE_VEC];
+	// all loads of the round in flight before the first LDS write
+#pragma unroll
+	for ( int i = 0; i < STAGE_VEC; i++ ) {
+	    const uint32_t v = v0 + i * BLOCK + threadIdx.x;
+	    const uint32_t a = org4 + ( v << 2 );
+	    float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	    if ( v < nvec ) {
+		if ( a + 3 < N && a + 3 >= a ) {
+		    s = *reinterpret_cast<const float4 *>(x + a);
+		} else {
+		    s.x = a < N ? x[a] : 0.0f;
+		    s.y = ( a + 1 < N && a + 1 > a ) ? x[a + 1] : 0.0f;
+		    s.z = ( a + 2 < N && a + 2 > a ) ? x[a + 2] : 0.0f;
+		    s.w = ( a + 3 < N && a + 3 > a ) ? x[a + 3] : 0.0f;
+		}
+	    }
+	    buf[i] = s;
+	}
+#pragma unroll
+	for ( int i = 0; i < STAGE_VEC; i++ ) {
+	    const uint32_t v = v0 + i * BLOCK + threadIdx.x;
+	    if ( v < nvec ) {
+		const uint32_t first = v << 2;		// index relative to org4
+		const float e[4] = { buf[i].x, buf[i].y, buf[i].z, buf[i].w };
+		// quotient/remainder of the first in-range element, then step
+		const uint32_t rel0 = first >= head ? first - head : 0u;
+		uint32_t q, r;
+		divmod_bit(cfg, rel0, q, r);
+		uint32_t idx = rel0 + q * skew;
+#pragma unroll
+		for ( int j = 0; j < 4; j++ ) {
+		    const uint32_t rel = first + j - head;	// valid when first + j >= head
+		    if ( first + j >= head && rel < slab_cap ) {
+			slab[idx] = e[j];
+			idx++;
+			if ( ++r == B ) {
+			    r = 0;
+			    idx += skew;
+			}
+		    }
+		}
+	    }
+	}
+    }
+}
+
+// Correlate every bit window of candidates c_pos[0..nq) (all threads; one lane
+// per window, the twiddle index n is uniform so twiddles arrive through the
+// scalar cache).  The twiddle table is zero-padded to a multiple of XCH, so the
+// tail of the last chunk contributes fma(x, 0, acc) == acc; its sample index is
+// clamped so that it never touches unstaged LDS.
 template <bool USE_SLAB>
-struct StreamCtx {
+__device__ void par_correlate( const DevCfg &cfg, const double *__restrict__ tw, StreamLds *lds,
+	const float *__restrict__ x, uint32_t N, uint32_t row_org, uint32_t nq )
+{
+    const uint32_t n_bits = cfg.n_bits;
+    const uint32_t B = cfg.bit_nsamples;
+    const uint32_t nwin = nq * n_bits;
+    for ( uint32_t w0 = 0; w0 < nwin; w0 += BLOCK ) {
+	const uint32_t w = w0 + threadIdx.x;
+	const bool active = w < nwin;
+	const uint32_t q = active ? w / n_bits : 0;
+	const uint32_t k = active ? w - q * n_bits : 0;
+	const uint32_t a = lds->c_pos[q] + cfg.bit_offset[k];
+	double mr = 0.0, mi = 0.0, sr = 0.0, si = 0.0;
+	if ( USE_SLAB ) {
+	    uint32_t row, col;
+	    divmod_bit(cfg, a - row_org, row, col);
+	    const float *p = lds->slab + ( a - row_org ) + row * cfg.skew;
+	    const uint32_t last = B - 1;
+	    if ( __all(!active || col == 0u) ) {
+		// every window of this wave starts on a row boundary (the run-ahead
+		// frames of a locked carrier): plain immediate-offset reads
+		for ( uint32_t n0 = 0; n0 < B; n0 += XCH ) {
+		    float xs[XCH];
+#pragma unroll
+		    for ( int j = 0; j < XCH; j++ )
+			xs[j] = p[n0 + j < last ? n0 + j : last];
+		    const double *t = tw + 4 * (size_t)n0;
+#pragma unroll
+		    for ( int j = 0; j < XCH; j++ ) {
+			const double xd = (double)xs[j];
+			mr = fma(xd, t[4 * j + 0], mr);
+			mi = fma(xd, t[4 * j + 1], mi);
+			sr = fma(xd, t[4 * j + 2], sr);
+			si = fma(xd, t[4 * j + 3], si);
+		    }
+		}
+	    } else {
+		const uint32_t wrap = B - col;	// first n that falls into the next row
+		const uint32_t skew = cfg.skew;
+		for ( uint32_t n0 = 0; n0 < B; n0 += XCH ) {
+		    float xs[XCH];
+#pragma unroll
+		    for ( int j = 0; j < XCH; j++ ) {
+			const uint32_t n = n0 + j < last ? n0 + j : last;	// uniform
+			xs[j] = p[n + ( n >= wrap ? skew : 0u )];
+		    }
+		    const double *t = tw + 4 * (size_t)n0;
+#pragma unroll
+		    for ( int j = 0; j < XCH; j++ ) {
+			const double xd = (double)xs[j];
+			mr = fma(xd, t[4 * j + 0], mr);
+			mi = fma(xd, t[4 * j + 1], mi);
+			sr = fma(xd, t[4 * j + 2], sr);
+			si = fma(xd, t[4 * j + 3], si);
+		    }
+		}
+	    }
+	} else {
+	    for ( uint32_t n = 0; n < B; n++ ) {
+		const uint32_t idx = a + n;
+		const float xv = ( idx < N && idx >= a ) ? x[idx] : 0.0f;
+		const double xd = (double)xv;
+		const double *t = tw + 4 * (size_t)n;
+		mr = fma(xd, t[0], mr);
+		mi = fma(xd, t[1], mi);
+		sr = fma(xd, t[2], sr);
+		si = fma(xd, t[3], si);
+	    }
+	}
+	if ( active )
+	    lds->mags[w] = make_float2(band_mag(mr, mi, cfg.magscalar),
+				       band_mag(sr, si, cfg.magscalar));
+    }
+}
+
+// what every wave does between "command published" and "correlated"
+template <bool USE_SLAB>
+__device__ __forceinline__ void parallel_part( const DevCfg &cfg, const double *__restrict__ tw,
+	StreamLds *lds, const float *__restrict__ x, uint32_t N, uint32_t slab_cap )
+{
+    const uint32_t nq = lds->cmd_nq;
+    const uint32_t row_org = lds->cmd_row_org;
+    if ( USE_SLAB && lds->cmd_stage ) {
+	par_stage(cfg, lds, x, N, slab_cap, row_org);
+	__syncthreads();
+    }
+    par_correlate<USE_SLAB>(cfg, tw, lds, x, N, row_org, nq);
+    __syncthreads();
+}
+
+// LDS writes of this wave are visible to its other lanes in program order; this
+// only stops the compiler from moving accesses across the point
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <bool USE_SLAB>
+struct Master {
     const DevCfg	&cfg;
     const double	*tw;
     const float		*x;		// this stream's samples
@@ -282,123 +477,63 @@ struct StreamCtx {
     uint32_t		slab_cap;	// samples the slab can hold
     uint32_t		slab_lo, slab_hi;	// absolute range currently staged
     uint32_t		npredict;	// frames to run ahead (0 = none)
+    uint32_t		lane;
+    // work counters (written out only when the caller asked for them)
+    uint32_t		n_batches = 0, n_stages = 0, n_hits = 0, n_positions = 0;
+    uint64_t		cyc_par = 0, cyc_conf = 0;
 
-    __device__ __forceinline__ StreamCtx( const DevCfg &c, const double *t, const float *xs,
+    __device__ __forceinline__ Master( const DevCfg &c, const double *t, const float *xs,
 	    uint32_t n, StreamLds *l, uint32_t cap, uint32_t np )
 	: cfg(c), tw(t), x(xs), N(n), lds(l), slab_cap(cap), slab_lo(0), slab_hi(0),
-	  npredict(np) {}
+	  npredict(np), lane(threadIdx.x) {}
 
-    // LDS word of slab-relative sample a: rows of B samples, `skew` pad words
-    // between rows, so lanes one bit length apart land on different banks.
-    __device__ __forceinline__ uint32_t slab_index( uint32_t a ) const
+    // Evaluate candidates c_pos[0..nq) (already in LDS) that span [lo, hi);
+    // row_org is where slab row 0 goes IF the slab has to be restaged.
+    __device__ void evaluate( uint32_t nq, uint32_t kind, uint32_t lo, uint32_t hi, uint32_t row_org )
     {
-	return a + ( a / cfg.bit_nsamples ) * cfg.skew;
-    }
-
-    // stage [lo, lo + slab_cap) (lo rounded down to 16 B) into the slab
-    __device__ void stage( uint32_t lo )
-    {
-	__syncthreads();		// everyone is done reading the old contents
-	const uint32_t org = lo & ~3u;
-	float *slab = lds->slab;
-	const uint32_t nvec = slab_cap >> 2;
-	for ( uint32_t v = threadIdx.x; v < nvec; v += BLOCK ) {
-	    const uint32_t rel = v << 2;
-	    const uint32_t a = org + rel;
-	    float4 s;
-	    if ( a + 3 < N && a + 3 >= a ) {
-		s = *reinterpret_cast<const float4 *>(x + a);	// coalesced 16 B / lane
-	    } else {
-		s.x = a < N ? x[a] : 0.0f;
-		s.y = ( a + 1 < N && a + 1 > a ) ? x[a + 1] : 0.0f;
-		s.z = ( a + 2 < N && a + 2 > a ) ? x[a + 2] : 0.0f;
-		s.w = ( a + 3 < N && a + 3 > a ) ? x[a + 3] : 0.0f;
-	    }
-	    slab[slab_index(rel)] = s.x;
-	    slab[slab_index(rel + 1)] = s.y;
-	    slab[slab_index(rel + 2)] = s.z;
-	    slab[slab_index(rel + 3)] = s.w;
+	bool restage = false;
+	if ( USE_SLAB && ( lo < slab_lo || hi > slab_hi ) ) {
+	    restage = true;
+	    slab_lo = row_org;
+	    slab_hi = row_org + slab_cap;
+	    n_stages++;
 	}
-	slab_lo = org;
-	slab_hi = org + slab_cap;
-	__syncthreads();
-    }
-
-    // Evaluate candidate positions c_pos[0..nq) (already in LDS): bit windows
-    // -> magnitudes -> per-position confidence, results into the cache arrays.
-    __device__ void evaluate( uint32_t nq, uint32_t kind, uint32_t lo, uint32_t hi )
-    {
-	const uint32_t n_bits = cfg.n_bits;
-	const uint32_t B = cfg.bit_nsamples;
-	if ( USE_SLAB ) {
-	    if ( lo < slab_lo || hi > slab_hi )
-		stage(lo);
+	if ( lane == 0 ) {
+	    lds->cmd_op = 1;
+	    lds->cmd_nq = nq;
+	    lds->cmd_stage = restage ? 1u : 0u;
+	    lds->cmd_row_org = slab_lo;
 	}
-	const uint32_t nwin = nq * n_bits;
-	for ( uint32_t w0 = 0; w0 < nwin; w0 += BLOCK ) {
-	    const uint32_t w = w0 + threadIdx.x;
-	    const bool active = w < nwin;
-	    const uint32_t q = active ? w / n_bits : 0;
-	    const uint32_t k = active ? w - q * n_bits : 0;
-	    const uint32_t a = lds->c_pos[q] + cfg.bit_offset[k];
-	    double mr = 0.0, mi = 0.0, sr = 0.0, si = 0.0;
-	    if ( USE_SLAB ) {
-		const uint32_t rel = a - slab_lo;
-		const uint32_t row = rel / B;
-		const uint32_t col = rel - row * B;
-		const float *p = lds->slab + rel + row * cfg.skew;
-		const uint32_t wrap = B - col;	// first n that falls into the next row
-		const uint32_t skew = cfg.skew;
-		for ( uint32_t n = 0; n < B; n++ ) {
-		    const float xv = p[n + ( n >= wrap ? skew : 0u )];
-		    const double xd = (double)xv;
-		    const double *t = tw + 4 * (size_t)n;
-		    mr = fma(xd, t[0], mr);
-		    mi = fma(xd, t[1], mi);
-		    sr = fma(xd, t[2], sr);
-		    si = fma(xd, t[3], si);
-		}
-	    } else {
-		for ( uint32_t n = 0; n < B; n++ ) {
-		    const uint32_t idx = a + n;
-		    const float xv = ( idx < N && idx >= a ) ? x[idx] : 0.0f;
-		    const double xd = (double)xv;
-		    const double *t = tw + 4 * (size_t)n;
-		    mr = fma(xd, t[0], mr);
-		    mi = fma(xd, t[1], mi);
-		    sr = fma(xd, t[2], sr);
-		    si = fma(xd, t[3], si);
-		}
-	    }
-	    if ( active )
-		lds->mags[w] = make_float2(band_mag(mr, mi, cfg.magscalar),
-					   band_mag(sr, si, cfg.magscalar));
+	n_batches++;
+	n_positions += nq;
+	const uint64_t t_par = clock64();
+	__syncthreads();			// command (and c_pos[]) published
+	parallel_part<USE_SLAB>(cfg, tw, lds, x, N, slab_cap);
+	const uint64_t t_conf = clock64();
+	cyc_par += t_conf - t_par;
+	if ( lane < nq ) {
+	    const FrameOut f = frame_confidence(&lds->mags[lane * cfg.n_bits],
+						cfg.expect[kind], cfg.n_bits);
+	    lds->c_conf[lane] = f.conf;
+	    lds->c_ampl[lane] = f.ampl;
+	    lds->c_bits[lane] = f.bits;
 	}
-	__syncthreads();
-	if ( threadIdx.x < nq ) {
-	    const FrameOut f = frame_confidence(&lds->mags[threadIdx.x * n_bits],
-						cfg.expect[kind], n_bits);
-	    lds->c_conf[threadIdx.x] = f.conf;
-	    lds->c_ampl[threadIdx.x] = f.ampl;
-	    lds->c_bits[threadIdx.x] = f.bits;
-	}
-	__syncthreads();
+	wave_lds_sync();
+	cyc_conf += clock64() - t_conf;
     }
 
     // fsk_find_frame at cursor `base` (absolute), with run-ahead (see file header)
-    __device__ ScanResult scan( uint32_t base, uint32_t first, uint32_t tmax, uint32_t step,
+    __device__ ScanResult scan( uint32_t base, const ZigZag &zz, uint32_t first,
 	    float limit, uint32_t kind, bool may_predict )
     {
 	ScanResult r;
-	r.conf = 0.0f; r.ampl = 0.0f; r.bits = 0; r.start = 0; r.computed = 0;
-	const ZigZag zz(first, tmax, step);
+	r.conf = 0.0f; r.ampl = 0.0f; r.bits = 0; r.start = 0;
 	if ( zz.J == 0 )
 	    return r;
+	const uint32_t p0 = base + first;
 
 	// cache probe for the first candidate
 	{
-	    const uint32_t lane = threadIdx.x & 63u;
-	    const uint32_t p0 = base + first;
 	    const bool m = lane < lds->c_n && lds->c_kind == kind && lds->c_pos[lane] == p0;
 	    const unsigned long long b = __ballot(m);
 	    if ( b ) {
@@ -409,6 +544,7 @@ struct StreamCtx {
 		    r.ampl = lds->c_ampl[hit];
 		    r.bits = lds->c_bits[hit];
 		    r.start = first;
+		    n_hits++;
 		    return r;
 		}
 	    }
@@ -428,37 +564,44 @@ struct StreamCtx {
 	    }
 	    const uint32_t lo = base + tlo;
 	    uint32_t hi = base + thi + cfg.last_reach;
+	    // Row 0 of a restaged slab: on the bit grid of the first candidate,
+	    // so that the run-ahead windows (whole bits away from it) start on
+	    // row boundaries.
+	    uint32_t row_org = lo;
+	    if ( p0 >= lo ) {
+		const uint32_t back = ( p0 - lo + cfg.bit_nsamples - 1 ) / cfg.bit_nsamples
+				    * cfg.bit_nsamples;
+		// only if the candidates themselves still fit behind the shifted origin
+		if ( p0 >= back && hi - ( p0 - back ) <= slab_cap )
+		    row_org = p0 - back;
+	    }
 	    // run-ahead: the next frames' first-try positions
 	    uint32_t M = 0;
 	    if ( may_predict && c0 == 0 && zz.J <= qmax ) {
 		M = qmax - Q < npredict ? qmax - Q : npredict;
-		const uint32_t p0 = base + first;
 		if ( USE_SLAB ) {
-		    const uint32_t org = lo & ~3u;
-		    const uint32_t used = ( p0 - org ) + cfg.last_reach;
-		    const uint32_t fit = used < slab_cap ? ( slab_cap - used ) / cfg.frame_nsamples : 0;
+		    const uint32_t used = ( p0 - row_org ) + cfg.last_reach;
+		    const uint32_t fit = used < slab_cap ? ( slab_cap - used ) / cfg.lock_advance : 0;
 		    M = M < fit ? M : fit;
 		}
 		// nothing to gain past the end of the stream
-		const uint32_t left = p0 < N ? ( N - p0 ) / cfg.frame_nsamples : 0;
+		const uint32_t left = p0 < N ? ( N - p0 ) / cfg.lock_advance : 0;
 		M = M < left ? M : left;
 		if ( M ) {
-		    const uint32_t ph = p0 + M * cfg.frame_nsamples + cfg.last_reach;
+		    const uint32_t ph = p0 + M * cfg.lock_advance + cfg.last_reach;
 		    hi = ph > hi ? ph : hi;
 		}
 	    }
-	    __syncthreads();		// all waves are past their cache probe / replay
-	    if ( threadIdx.x < Q )
-		lds->c_pos[threadIdx.x] = base + zz.at(c0 + threadIdx.x);
-	    else if ( threadIdx.x < Q + M )
-		lds->c_pos[threadIdx.x] = base + first + ( threadIdx.x - Q + 1 ) * cfg.frame_nsamples;
-	    if ( threadIdx.x == 0 ) {
+	    if ( lane < Q )
+		lds->c_pos[lane] = base + zz.at(c0 + lane);
+	    else if ( lane < Q + M )
+		lds->c_pos[lane] = p0 + ( lane - Q + 1 ) * cfg.lock_advance;
+	    if ( lane == 0 ) {
 		lds->c_n = Q + M;
+		lds->c_q = Q;
 		lds->c_kind = kind;
 	    }
-	    __syncthreads();
-	    evaluate(Q + M, kind, lo, hi);
-	    r.computed = 1;
+	    evaluate(Q + M, kind, lo, hi, row_org);
 	    for ( uint32_t i = 0; i < Q; i++ ) {	// fsk.c:492-501
 		const float c = lds->c_conf[i];
 		if ( r.conf < c ) {
@@ -496,31 +639,52 @@ __device__ __forceinline__ uint64_t bit_reverse( uint64_t v, uint32_t bits )
     return out;
 }
 
-template <bool USE_SLAB>
-__global__ __launch_bounds__(BLOCK)
-void demod_kernel( DevCfg cfg, const double *__restrict__ tw, mifsk_demod_io io,
-	uint32_t slab_cap, uint32_t npredict )
+// frame word -> data bits handed to the databits decoder (minimodem.c:1415-1428)
+__device__ __forceinline__ uint64_t data_bits_of( const DevCfg &cfg, uint64_t bits )
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    StreamLds *lds = reinterpret_cast<StreamLds *>(smem);
+    if ( cfg.has_stopbits )
+	bits >>= 1;
+    bits = bit_window(bits, cfg.nstartbits, cfg.n_data_bits);
+    if ( cfg.msb_first )
+	bits = bit_reverse(bits, cfg.n_data_bits);
+    return bits;
+}
 
+struct StreamOut {
+    uint8_t		*bytes;
+    uint64_t		*bits;
+    mifsk_frame		*frames;
+    mifsk_episode	*eps;
+    size_t		fcap, ecap;
+};
+
+__device__ __forceinline__ float lane_bcast( float v, uint32_t src )
+{
+    return __builtin_bit_cast(float,
+	    __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)src));
+}
+
+// The reference's receive loop (minimodem.c:1137-1463); executed by wave 0 only.
+template <bool USE_SLAB>
+__device__ void master_loop( const DevCfg &cfg, const double *__restrict__ tw,
+	const mifsk_demod_io &io, uint32_t slab_cap, uint32_t npredict, StreamLds *lds )
+{
     const uint32_t s = blockIdx.x;
     const float *x = io.d_samples + (size_t)s * io.stream_stride;
     const uint32_t N = io.d_nsamples ? io.d_nsamples[s] : io.nsamples;
-    const size_t fcap = io.frames_cap, ecap = io.episodes_cap;
-    uint8_t *o_bytes = io.d_bytes ? io.d_bytes + (size_t)s * fcap : nullptr;
-    uint64_t *o_bits = io.d_bits ? io.d_bits + (size_t)s * fcap : nullptr;
-    mifsk_frame *o_frames = io.d_frames ? io.d_frames + (size_t)s * fcap : nullptr;
-    mifsk_episode *o_eps = io.d_episodes ? io.d_episodes + (size_t)s * ecap : nullptr;
-    const bool t0 = threadIdx.x == 0;
+    StreamOut o;
+    o.fcap = io.frames_cap;
+    o.ecap = io.episodes_cap;
+    o.bytes = io.d_bytes ? io.d_bytes + (size_t)s * o.fcap : nullptr;
+    o.bits = io.d_bits ? io.d_bits + (size_t)s * o.fcap : nullptr;
+    o.frames = io.d_frames ? io.d_frames + (size_t)s * o.fcap : nullptr;
+    o.eps = io.d_episodes ? io.d_episodes + (size_t)s * o.ecap : nullptr;
+    const uint32_t lane = threadIdx.x;
+    const bool t0 = lane == 0;
 
-    if ( t0 )
-	lds->c_n = 0;
-    __syncthreads();
+    Master<USE_SLAB> ctx(cfg, tw, x, N, lds, slab_cap, npredict);
 
-    StreamCtx<USE_SLAB> ctx(cfg, tw, x, N, lds, slab_cap, npredict);
-
-    // reference loop state (minimodem.c:1079-1088,1132-1133)
+    // reference loop state (minimodem.c:1079-1088,1132-1133), uniform in the wave
     bool carrier = false;
     float confidence_total = 0.0f, amplitude_total = 0.0f;
     uint32_t nframes_decoded = 0;
@@ -532,8 +696,135 @@ void demod_kernel( DevCfg cfg, const double *__restrict__ tw, mifsk_demod_io io,
     uint32_t base = 0;			// absolute index of samplebuf[0]
     uint32_t n_out_frames = 0, n_out_bytes = 0, n_out_eps = 0, ep_first = 0;
     uint32_t status = 0;
+    uint32_t n_iter = 0, n_bulk = 0, n_refine = 0;
+    uint64_t cyc_bulk = 0;
+    const uint64_t t_start = clock64();
+
+    const ZigZag zc0(cfg.try_first[0], cfg.try_max[0], cfg.try_step[0]);
+    const ZigZag zc1(cfg.try_first[1], cfg.try_max[1], cfg.try_step[1]);
+    const ZigZag zf0(cfg.try_first[0], cfg.try_max[0], cfg.try_step_fine[0]);
+    const ZigZag zf1(cfg.try_first[1], cfg.try_max[1], cfg.try_step_fine[1]);
 
     for (;;) {
+	// ------------------------------------------------------------------
+	// Bulk acceptance of run-ahead frames.  While carrier is held and the
+	// cursor lands where the run-ahead assumed, the reference's iteration
+	// for frame k reduces to: first try wins the coarse scan (c >= limit),
+	// no refine (c >= 0.75 peak), no squelch (a >= 0.25 track, c > thr).
+	// Those predicates and the f32 state recurrences are replayed here in
+	// frame order from the cached (confidence, amplitude) pairs; the first
+	// frame that fails any of them falls through to the general path below.
+	// ------------------------------------------------------------------
+	if ( carrier && advance && advance <= N - base ) {
+	    const uint64_t t_bulk = clock64();
+	    const uint32_t first = cfg.try_first[1];
+	    const uint32_t nb = base + advance;		// cursor of the next iteration
+	    const uint32_t p = nb + first;
+	    const uint32_t cn = lds->c_n, cq = lds->c_q;
+	    const bool m = lane >= cq && lane < cn && lds->c_kind == 0u && lds->c_pos[lane] == p;
+	    const unsigned long long bal = __ballot(m);
+	    if ( bal ) {
+		const uint32_t e0 = (uint32_t)__ffsll((long long)bal) - 1u;
+		uint32_t K = cn - e0;
+		// frame k sits at cursor nb + k*lock_advance and needs expect_nsamples from there
+		const uint32_t fn = cfg.frame_nsamples;
+		const uint32_t la = cfg.lock_advance;
+		const uint32_t room = N - nb >= cfg.expect_nsamples
+				    ? ( N - nb - cfg.expect_nsamples ) / la + 1u : 0u;
+		K = K < room ? K : room;
+		// this lane's candidate (lane k <-> entry e0 + k)
+		const bool have = lane < K;
+		const float cv = have ? lds->c_conf[e0 + lane] : 0.0f;
+		const float av = have ? lds->c_ampl[e0 + lane] : 0.0f;
+		// Replay the f32 state recurrences over all K candidates without
+		// branching; lane k keeps the state as it was BEFORE frame k.  The
+		// values recorded for frames up to the first rejected one do not
+		// depend on anything after it, so they are exact.
+		float t = track_amplitude, pk = peak_confidence;
+		float sc = confidence_total, sa = amplitude_total;
+		float my_t = t, my_pk = pk, my_sc = sc, my_sa = sa;
+		for ( uint32_t k = 0; k < K; k++ ) {
+		    const float c = lane_bcast(cv, k);
+		    const float a = lane_bcast(av, k);
+		    const bool me = lane == k;
+		    my_t = me ? t : my_t;
+		    my_pk = me ? pk : my_pk;
+		    my_sc = me ? sc : my_sc;
+		    my_sa = me ? sa : my_sa;
+		    t = ( t + a ) / 2.0f;			// minimodem.c:1391
+		    pk = pk < c ? c : pk;			// minimodem.c:1392-1393
+		    sc += c;					// minimodem.c:1397-1398
+		    sa += a;
+		}
+		const bool ok = have
+		    && cv > 0.0f && cv >= cfg.search_limit	// fsk.c:492,499: first try ends the scan
+		    && !( cv < my_pk * 0.75f )			// minimodem.c:1278
+		    && !( av < my_t * 0.25f )			// minimodem.c:1286
+		    && !( cv <= cfg.conf_threshold );		// minimodem.c:1292
+		const unsigned long long bad = __ballot(have && !ok);
+		const uint32_t n = bad ? (uint32_t)__ffsll((long long)bad) - 1u : K;
+		float track, peak, ctot, atot;
+		if ( n == K ) {
+		    track = t; peak = pk; ctot = sc; atot = sa;
+		} else {
+		    track = lane_bcast(my_t, n);
+		    peak = lane_bcast(my_pk, n);
+		    ctot = lane_bcast(my_sc, n);
+		    atot = lane_bcast(my_sa, n);
+		}
+		if ( n ) {
+		    // outputs of frames 0..n-1, one lane each
+		    const bool mine = lane < n;
+		    uint64_t db = 0;
+		    bool suppressed = false;
+		    if ( mine ) {
+			db = data_bits_of(cfg, lds->c_bits[e0 + lane]);
+			suppressed = cfg.do_rx_sync && db == cfg.sync_byte;
+		    }
+		    const unsigned long long keep = __ballot(mine && !suppressed);
+		    if ( mine ) {
+			const uint32_t fi = n_out_frames + lane;
+			if ( fi < o.fcap ) {
+			    if ( o.bits )
+				o.bits[fi] = db;
+			    if ( o.frames ) {
+				mifsk_frame f;
+				f.bits = db;
+				f.start = (uint64_t)nb + (uint64_t)lane * la + first;
+				f.confidence = cv;
+				f.amplitude = av;
+				f.flags = suppressed ? MIFSK_FRAME_SYNC : 0u;
+				f.reserved = 0;
+				o.frames[fi] = f;
+			    }
+			}
+			if ( !suppressed && o.bytes ) {
+			    const uint32_t bi = n_out_bytes
+				+ (uint32_t)__popcll(keep & ( ( 1ULL << lane ) - 1ULL ));
+			    if ( bi < o.fcap )
+				o.bytes[bi] = (uint8_t)( db & 0xFFu );
+			}
+		    }
+		    n_out_frames += n;
+		    n_out_bytes += (uint32_t)__popcll(keep);
+		    // state after n trivially accepted frames: each advanced the
+		    // cursor by lock_advance = first + fn - overscan and added
+		    // fn + first - overscan to carrier_nsamples (minimodem.c:1324-1330,1407)
+		    track_amplitude = track;
+		    peak_confidence = peak;
+		    confidence_total = ctot;
+		    amplitude_total = atot;
+		    nframes_decoded += n;
+		    noconfidence = 0;
+		    carrier_nsamples += (uint64_t)n * ( fn + first - cfg.overscan );
+		    base = nb + ( n - 1u ) * la;
+		    advance = la;
+		    n_bulk += n;
+		}
+	    }
+	    cyc_bulk += clock64() - t_bulk;
+	}
+
 	// minimodem.c:1150-1156,1176,1229 under flat addressing
 	if ( advance ) {
 	    if ( advance > N - base )
@@ -543,13 +834,14 @@ void demod_kernel( DevCfg cfg, const double *__restrict__ tw, mifsk_demod_io io,
 	const uint32_t avail = N - base;
 	if ( avail == 0 || avail < cfg.expect_nsamples )
 	    break;
+	n_iter++;
 
 	const uint32_t ci = carrier ? 1u : 0u;
 	const uint32_t try_max = cfg.try_max[ci];
 	const uint32_t try_step = cfg.try_step[ci];
 	const uint32_t try_first = cfg.try_first[ci];
 
-	ScanResult sr = ctx.scan(base, try_first, try_max, try_step, cfg.search_limit,
+	ScanResult sr = ctx.scan(base, carrier ? zc1 : zc0, try_first, cfg.search_limit,
 				 carrier ? 0u : 1u, carrier);	// minimodem.c:1265-1274
 	float confidence = sr.conf;
 	float amplitude = sr.ampl;
@@ -567,7 +859,7 @@ void demod_kernel( DevCfg cfg, const double *__restrict__ tw, mifsk_demod_io io,
 	if ( confidence <= cfg.conf_threshold ) {		// minimodem.c:1292-1321
 	    if ( ++noconfidence > 20u ) {
 		if ( carrier ) {
-		    if ( t0 && o_eps && n_out_eps < ecap ) {
+		    if ( t0 && o.eps && n_out_eps < o.ecap ) {
 			mifsk_episode e;
 			e.carrier_nsamples = carrier_nsamples;
 			e.first_frame = ep_first;
@@ -576,7 +868,7 @@ void demod_kernel( DevCfg cfg, const double *__restrict__ tw, mifsk_demod_io io,
 			e.amplitude_total = amplitude_total;
 			e.end_reason = 1;
 			e.reserved = 0;
-			o_eps[n_out_eps] = e;
+			o.eps[n_out_eps] = e;
 		    }
 		    n_out_eps++;
 		    carrier = false;
@@ -608,9 +900,9 @@ void demod_kernel( DevCfg cfg, const double *__restrict__ tw, mifsk_demod_io io,
 	if ( refine && confidence < INFINITY && try_step > 1u ) {	// minimodem.c:1357-1389
 	    // `carrier` is already set: an acquiring frame is re-searched with
 	    // the data string over the no-carrier range (minimodem.c:1378)
-	    ScanResult s2 = ctx.scan(base, try_first, try_max, cfg.try_step_fine[ci],
-				     INFINITY, 0u, false);
+	    ScanResult s2 = ctx.scan(base, ci ? zf1 : zf0, try_first, INFINITY, 0u, false);
 	    flags |= MIFSK_FRAME_REFINED;
+	    n_refine++;
 	    if ( s2.conf > confidence ) {
 		bits = s2.bits;
 		amplitude = s2.ampl;
@@ -628,21 +920,16 @@ void demod_kernel( DevCfg cfg, const double *__restrict__ tw, mifsk_demod_io io,
 
 	advance = frame_start + cfg.frame_nsamples - cfg.overscan;	// minimodem.c:1407
 
-	if ( cfg.has_stopbits )						// minimodem.c:1415-1428
-	    bits >>= 1;
-	bits = bit_window(bits, cfg.nstartbits, cfg.n_data_bits);
-	if ( cfg.msb_first )
-	    bits = bit_reverse(bits, cfg.n_data_bits);
-
+	bits = data_bits_of(cfg, bits);					// minimodem.c:1415-1428
 	const bool suppressed = cfg.do_rx_sync && bits == cfg.sync_byte;	// minimodem.c:1436-1439
 	if ( suppressed )
 	    flags |= MIFSK_FRAME_SYNC;
 
 	if ( t0 ) {
-	    if ( n_out_frames < fcap ) {
-		if ( o_bits )
-		    o_bits[n_out_frames] = bits;
-		if ( o_frames ) {
+	    if ( n_out_frames < o.fcap ) {
+		if ( o.bits )
+		    o.bits[n_out_frames] = bits;
+		if ( o.frames ) {
 		    mifsk_frame f;
 		    f.bits = bits;
 		    f.start = (uint64_t)base + frame_start;
@@ -650,11 +937,11 @@ void demod_kernel( DevCfg cfg, const double *__restrict__ tw, mifsk_demod_io io,
 		    f.amplitude = amplitude;
 		    f.flags = flags;
 		    f.reserved = 0;
-		    o_frames[n_out_frames] = f;
+		    o.frames[n_out_frames] = f;
 		}
 	    }
-	    if ( !suppressed && o_bytes && n_out_bytes < fcap )
-		o_bytes[n_out_bytes] = (uint8_t)( bits & 0xFFu );
+	    if ( !suppressed && o.bytes && n_out_bytes < o.fcap )
+		o.bytes[n_out_bytes] = (uint8_t)( bits & 0xFFu );
 	}
 	n_out_frames++;
 	if ( !suppressed )
@@ -662,7 +949,7 @@ void demod_kernel( DevCfg cfg, const double *__restrict__ tw, mifsk_demod_io io,
     }
 
     if ( carrier ) {						// minimodem.c:1469-1474
-	if ( t0 && o_eps && n_out_eps < ecap ) {
+	if ( t0 && o.eps && n_out_eps < o.ecap ) {
 	    mifsk_episode e;
 	    e.carrier_nsamples = carrier_nsamples;
 	    e.first_frame = ep_first;
@@ -671,19 +958,72 @@ void demod_kernel( DevCfg cfg, const double *__restrict__ tw, mifsk_demod_io io,
 	    e.amplitude_total = amplitude_total;
 	    e.end_reason = 2;
 	    e.reserved = 0;
-	    o_eps[n_out_eps] = e;
+	    o.eps[n_out_eps] = e;
 	}
 	n_out_eps++;
     }
     if ( t0 ) {
-	if ( n_out_frames > fcap && ( o_bits || o_frames || o_bytes ) )
+	if ( n_out_frames > o.fcap && ( o.bits || o.frames || o.bytes ) )
 	    status |= MIFSK_STREAM_FRAMES_TRUNCATED;
-	if ( n_out_eps > ecap && o_eps )
+	if ( n_out_eps > o.ecap && o.eps )
 	    status |= MIFSK_STREAM_EPISODES_TRUNCATED;
 	if ( io.d_nframes ) io.d_nframes[s] = n_out_frames;
 	if ( io.d_nbytes ) io.d_nbytes[s] = n_out_bytes;
 	if ( io.d_nepisodes ) io.d_nepisodes[s] = n_out_eps;
 	if ( io.d_status ) io.d_status[s] = status;
+	if ( io.d_counters ) {
+	    uint64_t *c = io.d_counters + (size_t)s * MIFSK_NCOUNTERS;
+	    for ( int i = 0; i < MIFSK_NCOUNTERS; i++ )
+		c[i] = 0;
+	    c[MIFSK_CNT_ITERATIONS] = n_iter;
+	    c[MIFSK_CNT_BATCHES] = ctx.n_batches;
+	    c[MIFSK_CNT_STAGES] = ctx.n_stages;
+	    c[MIFSK_CNT_BULK_FRAMES] = n_bulk;
+	    c[MIFSK_CNT_REFINES] = n_refine;
+	    c[MIFSK_CNT_CACHE_HITS] = ctx.n_hits;
+	    c[MIFSK_CNT_POSITIONS] = ctx.n_positions;
+	    c[MIFSK_CNT_CYC_TOTAL] = clock64() - t_start;
+	    c[MIFSK_CNT_CYC_PARALLEL] = ctx.cyc_par;
+	    c[MIFSK_CNT_CYC_CONFIDENCE] = ctx.cyc_conf;
+	    c[MIFSK_CNT_CYC_BULK] = cyc_bulk;
+	}
+    }
+}
+
+template <bool USE_SLAB>
+__global__ __launch_bounds__(BLOCK)
+void demod_kernel( DevCfg cfg, const double *__restrict__ tw, mifsk_demod_io io,
+	uint32_t slab_cap, uint32_t npredict )
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    StreamLds *lds = reinterpret_cast<StreamLds *>(smem);
+
+    if ( threadIdx.x == 0 ) {
+	lds->c_n = 0;
+	lds->c_q = 0;
+	lds->c_kind = 0;
+	lds->cmd_op = 1;
+    }
+    __syncthreads();
+
+    if ( threadIdx.x < 64 ) {
+	// the serial chain is the critical path of the workgroup: let it win
+	// issue arbitration against the (throughput-bound) worker waves
+	__builtin_amdgcn_s_setprio(3);
+	master_loop<USE_SLAB>(cfg, tw, io, slab_cap, npredict, lds);
+	if ( threadIdx.x == 0 )
+	    lds->cmd_op = 0;
+	__syncthreads();			// releases the workers with "exit"
+    } else {
+	const uint32_t s = blockIdx.x;
+	const float *x = io.d_samples + (size_t)s * io.stream_stride;
+	const uint32_t N = io.d_nsamples ? io.d_nsamples[s] : io.nsamples;
+	for (;;) {
+	    __syncthreads();			// a command has been published
+	    if ( lds->cmd_op == 0 )
+		break;
+	    parallel_part<USE_SLAB>(cfg, tw, lds, x, N, slab_cap);
+	}
     }
 }
 
@@ -768,13 +1108,13 @@ int launch_demod_batch( const DevCfg &cfg, const double *d_tw,
 
     uint32_t slab_cap = 0, npredict = 0;
     bool use_slab = true;
-    const uint32_t ideal = reach + want * cfg.frame_nsamples;
+    const uint32_t ideal = reach + want * cfg.lock_advance + B;
     if ( kLdsHeader + floats_for(ideal) * 4 <= budget_small ) {
 	slab_cap = ( ideal + 3 ) & ~3u;
 	npredict = want;
-    } else if ( samples_in(budget_small) >= reach + cfg.frame_nsamples ) {
+    } else if ( samples_in(budget_small) >= reach + cfg.lock_advance ) {
 	slab_cap = samples_in(budget_small);
-	npredict = ( slab_cap - reach ) / cfg.frame_nsamples;
+	npredict = ( slab_cap - reach ) / cfg.lock_advance;
 	if ( npredict > want ) npredict = want;
     } else {
 	// long bit windows: take as much LDS as one search needs (fewer WGs/CU)
