@@ -55,6 +55,20 @@ void fill_devcfg( DevCfg &d, const mifsk_rx_config &c )
     d.div_magic = c.bit_nsamples > 1 ? (uint32_t)( 0x100000000ULL / c.bit_nsamples ) : 0xFFFFFFFFu;
     // minimodem.c:1407 with frame_start == try_first (carrier)
     d.lock_advance = c.try_first[1] + c.frame_nsamples - c.nsamples_overscan;
+    d.la_magic = d.lock_advance > 1 ? (uint32_t)( 0x100000000ULL / d.lock_advance ) : 0xFFFFFFFFu;
+    d.nbits_magic = c.expect_n_bits > 1 ? (uint32_t)( 0x100000000ULL / c.expect_n_bits ) : 0xFFFFFFFFu;
+    {
+	// lowest candidate of the carrier coarse scan relative to its first try
+	// (fsk.c:477-484), rounded up to whole bit lengths
+	const unsigned f = c.try_first[1], mx = c.try_max[1], st = c.try_step[1];
+	unsigned down = 0;
+	if ( f < mx && st ) {
+	    const unsigned U = ( mx - f - 1 ) / st + 1;
+	    const unsigned D = U - 1 < f / st ? U - 1 : f / st;
+	    down = D * st;
+	}
+	d.lock_back = ( down + c.bit_nsamples - 1 ) / c.bit_nsamples * c.bit_nsamples;
+    }
     for ( unsigned k = 0; k < c.expect_n_bits; k++ ) {
 	d.bit_offset[k] = c.bit_offset[k];
 	for ( int s = 0; s < 2; s++ ) {

@@ -31,7 +31,9 @@ struct DevCfg {
     uint32_t	skew;			// LDS slab row padding (see mifsk_kernels.hip)
     uint32_t	div_magic;		// floor(2^32 / bit_nsamples)
     uint32_t	lock_advance;		// cursor step of a frame locked at its first try
-    uint32_t	pad0;
+    uint32_t	la_magic;		// floor(2^32 / lock_advance)
+    uint32_t	nbits_magic;		// floor(2^32 / n_bits)
+    uint32_t	lock_back;		// slab row 0 sits this far before a locked frame's first try
     uint32_t	bit_offset[MIFSK_MAX_FRAME_BITS];	// fsk.c:204
     uint8_t	expect[2][MIFSK_MAX_FRAME_BITS];	// [0]=data [1]=sync; 0,1 or 2 ('d')
 };

@@ -300,6 +300,15 @@ __device__ __forceinline__ void divmod_bit( const DevCfg &cfg, uint32_t rel, uin
     }
 }
 
+// x / d for a divisor whose magic = floor(2^32 / d) was computed on the host
+__device__ __forceinline__ uint32_t udiv_magic( uint32_t x, uint32_t d, uint32_t magic )
+{
+    uint32_t q = __umulhi(x, magic);
+    if ( x - q * d >= d )
+	q++;
+    return q;
+}
+
 // Stage samples [row_org, row_org + slab_cap) of the stream into the slab (all
 // threads).  Global reads are 16-byte aligned float4 (coalesced, 1 KiB per wave
 // instruction); the LDS word of sample a is rel + (rel / B) * skew with
@@ -377,7 +386,7 @@ __device__ void par_correlate( const DevCfg &cfg, const double *__restrict__ tw,
     for ( uint32_t w0 = 0; w0 < nwin; w0 += BLOCK ) {
 	const uint32_t w = w0 + threadIdx.x;
 	const bool active = w < nwin;
-	const uint32_t q = active ? w / n_bits : 0;
+	const uint32_t q = active ? udiv_magic(w, n_bits, cfg.nbits_magic) : 0;
 	const uint32_t k = active ? w - q * n_bits : 0;
 	const uint32_t a = lds->c_pos[q] + cfg.bit_offset[k];
 	double mr = 0.0, mi = 0.0, sr = 0.0, si = 0.0;
@@ -568,24 +577,20 @@ struct Master {
 	    // so that the run-ahead windows (whole bits away from it) start on
 	    // row boundaries.
 	    uint32_t row_org = lo;
-	    if ( p0 >= lo ) {
-		const uint32_t back = ( p0 - lo + cfg.bit_nsamples - 1 ) / cfg.bit_nsamples
-				    * cfg.bit_nsamples;
-		// only if the candidates themselves still fit behind the shifted origin
-		if ( p0 >= back && hi - ( p0 - back ) <= slab_cap )
-		    row_org = p0 - back;
-	    }
+	    if ( may_predict && p0 >= cfg.lock_back && p0 - cfg.lock_back <= lo
+		    && hi - ( p0 - cfg.lock_back ) <= slab_cap )
+		row_org = p0 - cfg.lock_back;
 	    // run-ahead: the next frames' first-try positions
 	    uint32_t M = 0;
 	    if ( may_predict && c0 == 0 && zz.J <= qmax ) {
 		M = qmax - Q < npredict ? qmax - Q : npredict;
 		if ( USE_SLAB ) {
 		    const uint32_t used = ( p0 - row_org ) + cfg.last_reach;
-		    const uint32_t fit = used < slab_cap ? ( slab_cap - used ) / cfg.lock_advance : 0;
+		    const uint32_t fit = used < slab_cap ? udiv_magic(slab_cap - used, cfg.lock_advance, cfg.la_magic) : 0;
 		    M = M < fit ? M : fit;
 		}
 		// nothing to gain past the end of the stream
-		const uint32_t left = p0 < N ? ( N - p0 ) / cfg.lock_advance : 0;
+		const uint32_t left = p0 < N ? udiv_magic(N - p0, cfg.lock_advance, cfg.la_magic) : 0;
 		M = M < left ? M : left;
 		if ( M ) {
 		    const uint32_t ph = p0 + M * cfg.lock_advance + cfg.last_reach;
@@ -730,7 +735,7 @@ __device__ void master_loop( const DevCfg &cfg, const double *__restrict__ tw,
 		const uint32_t fn = cfg.frame_nsamples;
 		const uint32_t la = cfg.lock_advance;
 		const uint32_t room = N - nb >= cfg.expect_nsamples
-				    ? ( N - nb - cfg.expect_nsamples ) / la + 1u : 0u;
+				    ? udiv_magic(N - nb - cfg.expect_nsamples, la, cfg.la_magic) + 1u : 0u;
 		K = K < room ? K : room;
 		// this lane's candidate (lane k <-> entry e0 + k)
 		const bool have = lane < K;

@@ -1,0 +1,91 @@
+"""The N>1 path on CPU: world_size-2 `gloo` processes exercise the stream
+sharding and the gather of decoded bytes to rank 0 (minimodem_amd.shard_range /
+gather_bytes -- the same code bench.py runs over RCCL on GPUs).  The demod
+kernel itself needs a GPU and is covered by the -m gpu tests; here each rank's
+"decoded bytes" come from the oracle so that the assembled result can be
+checked against a single-process decode of the whole batch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import _oracle as O
+import minimodem_amd as M
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make_batch(nstreams):
+    cfg = M.rx_config("1200")
+    rng = np.random.default_rng(99)
+    streams = []
+    for i in range(nstreams):
+        words = rng.integers(32, 127, size=20 + (i % 5), dtype=np.uint8)
+        streams.append((M.synthesize(cfg, words, leading_silence=i % 7), bytes(words)))
+    return streams
+
+
+def _worker(rank, world, port, nstreams, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        streams = _make_batch(nstreams)
+        lo, hi = M.shard_range(nstreams, rank, world)
+        ocfg = O.oracle_config("1200")
+        cap = 32
+        local = torch.zeros((hi - lo, cap), dtype=torch.uint8)
+        counts = torch.zeros(hi - lo, dtype=torch.int32)
+        for j, i in enumerate(range(lo, hi)):
+            b = O.oracle_rx_stream(ocfg, streams[i][0])["bytes"]
+            local[j, :len(b)] = torch.frombuffer(bytearray(b), dtype=torch.uint8)
+            counts[j] = len(b)
+        bufs, cnts = M.gather_bytes(local, counts, dst=0)
+        if rank == 0:
+            out = []
+            for bb, cc in zip(bufs, cnts):
+                for row, n in zip(bb.numpy(), cc.numpy()):
+                    out.append(row[:n].tobytes())
+            q.put(out)
+        else:
+            assert bufs is None and cnts is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nstreams", [7, 8])
+def test_two_rank_shard_and_gather(nstreams):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, nstreams, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expected = [w for _, w in _make_batch(nstreams)]
+    assert out == expected
+
+
+def test_shard_range_partitions_exactly():
+    for n in (0, 1, 7, 8, 1024, 65536):
+        for world in (1, 2, 3, 8):
+            spans = [M.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for a, b in zip(spans, spans[1:]):
+                assert a[1] == b[0]
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
