@@ -232,9 +232,11 @@ typedef struct mifsk_demod_io {
 #define MIFSK_CNT_BULK_FRAMES	3	/* frames accepted from the run-ahead    */
 #define MIFSK_CNT_REFINES	4	/* fine rescans                          */
 #define MIFSK_CNT_CACHE_HITS	5	/* searches answered from the cache      */
-#define MIFSK_CNT_POSITIONS	6	/* candidate positions evaluated         */
+#define MIFSK_CNT_POSITIONS	6	/* candidate positions evaluated (SCAN)  */
+#define MIFSK_CNT_LATTICE_BATCHES 7	/* pipelined lattice batches scored      */
 #define MIFSK_CNT_CYC_TOTAL	8
-#define MIFSK_CNT_CYC_PARALLEL	9	/* stage + correlate, incl. barriers     */
+#define MIFSK_CNT_CYC_PARALLEL	9	/* SCAN: stage + correlate + barriers    */
+#define MIFSK_CNT_CYC_WAIT	10	/* LATTICE: master waiting for workers   */
 #define MIFSK_CNT_CYC_CONFIDENCE 11
 #define MIFSK_CNT_CYC_BULK	12
 

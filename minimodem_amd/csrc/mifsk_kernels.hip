@@ -37,7 +37,7 @@ namespace mifsk {
 
 constexpr int BLOCK = 256;	// threads per stream workgroup (4 waves)
 constexpr int P_CAP = 64;	// candidate positions per batch (= one wave of lanes)
-constexpr int W_CAP = 512;	// bit windows per batch (LDS scratch)
+constexpr int W_CAP = 256;	// bit windows per batch (LDS scratch)
 
 // ---------------------------------------------------------------------------
 // arithmetic shared by every kernel
@@ -251,32 +251,62 @@ void find_frame_kernel( DevCfg cfg, const double *__restrict__ tw,
 }
 
 // ---------------------------------------------------------------------------
-// kernel 2: the receive loop, one workgroup per stream
+// kernel 2: the receive loop, one workgroup (4 waves) per stream
 //
-// Wave 0 is the MASTER: it owns the reference's loop state and runs the serial
-// decision logic.  Waves 1..3 are WORKERS: they only ever execute the two
-// data-parallel steps (stage the LDS slab, correlate bit windows), driven by a
-// command block in LDS.  Every wave meets at the same sequence of s_barriers
-// (command published -> [staged] -> correlated), so the serial logic costs one
-// wave's issue slots instead of four.
+// Wave 0 is the MASTER: it owns the reference's loop state (minimodem.c:
+// 1079-1133) and runs the serial decision logic.  Waves 1..3 are WORKERS: they
+// turn audio into per-bit magnitudes.  Two protocols connect them, selected by
+// a command block in LDS that the master publishes before a barrier:
+//
+//  LATTICE (steady state, pipelined).  Once carrier is held, frame k+1 is
+//    searched first at exactly lock_advance samples after frame k (minimodem.c:
+//    1263,1407) and that first try is accepted whenever its confidence reaches
+//    the search limit (fsk.c:499) -- the normal case.  So the positions that
+//    will be asked for lie on a lattice.  Workers evaluate a batch of P
+//    consecutive lattice frames: each worker wave stages the audio its own 64
+//    bit windows need into a private LDS region (coalesced 16-byte loads, no
+//    cross-wave dependency) and correlates them, one lane per window.  One
+//    barrier per batch: while the workers correlate batch k+1 the master
+//    scores batch k (per-frame confidence, then the acceptance predicates and
+//    f32 state recurrences replayed in frame order).
+//  SCAN (acquisition, refinement, anything off the lattice).  The reference's
+//    fsk_find_frame for one cursor: all four waves stage one slab and evaluate
+//    every candidate position of the zig-zag scan, synchronously.
+//
+// Nothing ever depends on the speculation being right: a frame that fails any
+// predicate is handed to the general path, which recomputes from the samples.
 // ---------------------------------------------------------------------------
 
+constexpr int NWORKERS = 3;
+constexpr int LAT_LANES = NWORKERS * 64;	// bit windows per lattice batch
+
 struct StreamLds {
-    float2	mags[W_CAP];
+    float2	mags[2][W_CAP];	// [buffer][window]: (mark, space) magnitudes
     uint64_t	c_bits[P_CAP];
     float	c_conf[P_CAP];
     float	c_ampl[P_CAP];
     uint32_t	c_pos[P_CAP];
     uint32_t	c_n;		// valid cache entries
     uint32_t	c_kind;		// expect string they were evaluated with
-    uint32_t	c_q;		// entries [c_q, c_n) are run-ahead frames, lock_advance apart
-    uint32_t	cmd_op;		// 0: exit, 1: evaluate c_pos[0..cmd_nq)
-    uint32_t	cmd_nq;
-    uint32_t	cmd_stage;	// 1: restage the slab at cmd_row_org first
-    uint32_t	cmd_row_org;	// absolute sample index of slab row 0
+    uint32_t	c_q;		// entries [c_q, c_n) are consecutive lattice frames
     uint32_t	pad;
+    // Two command slots used alternately: the one published before barrier
+    // number n is slot n & 1, so a slot is rewritten only after every wave has
+    // passed another barrier and is done reading it.
+    struct Cmd {
+	uint32_t	op;		// CMD_*
+	uint32_t	nq;		// SCAN: candidates in c_pos[]
+	uint32_t	stage;		// SCAN: restage the slab at row_org first
+	uint32_t	row_org;	// SCAN: absolute sample index of slab row 0
+	uint32_t	anchor;		// LATTICE: first-try position of frame 0
+	uint32_t	frames;		// LATTICE: frames in the batch
+	uint32_t	buf;		// LATTICE: mags[] buffer to fill
+	uint32_t	pad;
+    }		cmd[2];
     float	slab[1];	// really slab_floats long (dynamic LDS)
 };
+
+enum { CMD_EXIT = 0, CMD_SCAN = 1, CMD_LATTICE = 2, CMD_IDLE = 3 };
 
 struct ScanResult {
     float	conf;
@@ -309,73 +339,131 @@ __device__ __forceinline__ uint32_t udiv_magic( uint32_t x, uint32_t d, uint32_t
     return q;
 }
 
-// Stage samples [row_org, row_org + slab_cap) of the stream into the slab (all
-// threads).  Global reads are 16-byte aligned float4 (coalesced, 1 KiB per wave
-// instruction); the LDS word of sample a is rel + (rel / B) * skew with
-// rel = a - row_org: rows of one bit length with `skew` pad words in between,
-// so lanes whose windows start a whole number of bits apart read different
-// banks.  Samples at or beyond N are zero.
+__device__ __forceinline__ float4 load4_guarded( const float *__restrict__ x, uint32_t a, uint32_t N )
+{
+    float4 s;
+    if ( a + 3 < N && a + 3 >= a ) {
+	s = *reinterpret_cast<const float4 *>(x + a);	// 16 B per lane, coalesced
+    } else {
+	s.x = a < N ? x[a] : 0.0f;
+	s.y = ( a + 1 < N && a + 1 > a ) ? x[a + 1] : 0.0f;
+	s.z = ( a + 2 < N && a + 2 > a ) ? x[a + 2] : 0.0f;
+	s.w = ( a + 3 < N && a + 3 > a ) ? x[a + 3] : 0.0f;
+    }
+    return s;
+}
+
+// Write the 4 samples of the float4 that sits `first` samples after org4 into a
+// skewed slab whose row 0 starts `head` samples after org4.  The LDS word of
+// slab-relative sample rel is rel + (rel / B) * skew: rows of one bit length
+// with `skew` pad words in between, so lanes whose windows start a whole number
+// of bits apart read different banks.
+__device__ __forceinline__ void store4_skewed( const DevCfg &cfg, float *slab, uint32_t cap,
+	uint32_t first, uint32_t head, const float4 &s )
+{
+    const uint32_t B = cfg.bit_nsamples, skew = cfg.skew;
+    const float e[4] = { s.x, s.y, s.z, s.w };
+    const uint32_t rel0 = first >= head ? first - head : 0u;
+    uint32_t q, r;
+    divmod_bit(cfg, rel0, q, r);
+    uint32_t idx = rel0 + q * skew;
+#pragma unroll
+    for ( int j = 0; j < 4; j++ ) {
+	const uint32_t rel = first + j - head;		// meaningful when first + j >= head
+	if ( first + j >= head && rel < cap ) {
+	    slab[idx] = e[j];
+	    idx++;
+	    if ( ++r == B ) {
+		r = 0;
+		idx += skew;
+	    }
+	}
+    }
+}
+
+// The two-band correlation of ONE bit window held in a skewed slab (one lane).
+// `rel` is the window start relative to slab row 0.  The twiddle index is
+// uniform across the wave, so the twiddles arrive through the scalar cache; the
+// table is zero-padded to a multiple of XCH and the tail of the last chunk
+// contributes fma(x, 0, acc) == acc (its sample index is clamped so that it
+// never reads LDS that was not staged).
+__device__ __forceinline__ void correlate_window( const DevCfg &cfg, const double *__restrict__ tw,
+	const float *slab, uint32_t rel, bool active, double acc[4] )
+{
+    const uint32_t B = cfg.bit_nsamples;
+    uint32_t row, col;
+    divmod_bit(cfg, rel, row, col);
+    const float *p = slab + rel + row * cfg.skew;
+    const uint32_t last = B - 1;
+    double mr = 0.0, mi = 0.0, sr = 0.0, si = 0.0;
+    if ( __all(!active || col == 0u) ) {
+	// every window of this wave starts on a row boundary: plain
+	// immediate-offset LDS reads, no per-sample address arithmetic
+	for ( uint32_t n0 = 0; n0 < B; n0 += XCH ) {
+	    float xs[XCH];
+#pragma unroll
+	    for ( int j = 0; j < XCH; j++ )
+		xs[j] = p[n0 + j < last ? n0 + j : last];
+	    const double *t = tw + 4 * (size_t)n0;
+#pragma unroll
+	    for ( int j = 0; j < XCH; j++ ) {
+		const double xd = (double)xs[j];
+		mr = fma(xd, t[4 * j + 0], mr);
+		mi = fma(xd, t[4 * j + 1], mi);
+		sr = fma(xd, t[4 * j + 2], sr);
+		si = fma(xd, t[4 * j + 3], si);
+	    }
+	}
+    } else {
+	const uint32_t wrap = B - col;	// first n that falls into the next row
+	const uint32_t skew = cfg.skew;
+	for ( uint32_t n0 = 0; n0 < B; n0 += XCH ) {
+	    float xs[XCH];
+#pragma unroll
+	    for ( int j = 0; j < XCH; j++ ) {
+		const uint32_t n = n0 + j < last ? n0 + j : last;	// uniform
+		xs[j] = p[n + ( n >= wrap ? skew : 0u )];
+	    }
+	    const double *t = tw + 4 * (size_t)n0;
+#pragma unroll
+	    for ( int j = 0; j < XCH; j++ ) {
+		const double xd = (double)xs[j];
+		mr = fma(xd, t[4 * j + 0], mr);
+		mi = fma(xd, t[4 * j + 1], mi);
+		sr = fma(xd, t[4 * j + 2], sr);
+		si = fma(xd, t[4 * j + 3], si);
+	    }
+	}
+    }
+    acc[0] = mr; acc[1] = mi; acc[2] = sr; acc[3] = si;
+}
+
+// SCAN: stage samples [row_org, row_org + slab_cap) into the slab (all threads)
 __device__ void par_stage( const DevCfg &cfg, StreamLds *lds, const float *__restrict__ x,
 	uint32_t N, uint32_t slab_cap, uint32_t row_org )
 {
     const uint32_t org4 = row_org & ~3u;
     const uint32_t head = row_org - org4;		// 0..3 samples before row 0: dropped
-    float *slab = lds->slab;
     const uint32_t nvec = ( slab_cap + head + 3 ) >> 2;
-    const uint32_t B = cfg.bit_nsamples, skew = cfg.skew;
     for ( uint32_t v0 = 0; v0 < nvec; v0 += BLOCK * STAGE_VEC ) {
 	float4 buf[STAGE_VEC];
 	// all loads of the round in flight before the first LDS write
 #pragma unroll
 	for ( int i = 0; i < STAGE_VEC; i++ ) {
 	    const uint32_t v = v0 + i * BLOCK + threadIdx.x;
-	    const uint32_t a = org4 + ( v << 2 );
-	    float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-	    if ( v < nvec ) {
-		if ( a + 3 < N && a + 3 >= a ) {
-		    s = *reinterpret_cast<const float4 *>(x + a);
-		} else {
-		    s.x = a < N ? x[a] : 0.0f;
-		    s.y = ( a + 1 < N && a + 1 > a ) ? x[a + 1] : 0.0f;
-		    s.z = ( a + 2 < N && a + 2 > a ) ? x[a + 2] : 0.0f;
-		    s.w = ( a + 3 < N && a + 3 > a ) ? x[a + 3] : 0.0f;
-		}
-	    }
-	    buf[i] = s;
+	    buf[i] = v < nvec ? load4_guarded(x, org4 + ( v << 2 ), N)
+			      : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 	}
 #pragma unroll
 	for ( int i = 0; i < STAGE_VEC; i++ ) {
 	    const uint32_t v = v0 + i * BLOCK + threadIdx.x;
-	    if ( v < nvec ) {
-		const uint32_t first = v << 2;		// index relative to org4
-		const float e[4] = { buf[i].x, buf[i].y, buf[i].z, buf[i].w };
-		// quotient/remainder of the first in-range element, then step
-		const uint32_t rel0 = first >= head ? first - head : 0u;
-		uint32_t q, r;
-		divmod_bit(cfg, rel0, q, r);
-		uint32_t idx = rel0 + q * skew;
-#pragma unroll
-		for ( int j = 0; j < 4; j++ ) {
-		    const uint32_t rel = first + j - head;	// valid when first + j >= head
-		    if ( first + j >= head && rel < slab_cap ) {
-			slab[idx] = e[j];
-			idx++;
-			if ( ++r == B ) {
-			    r = 0;
-			    idx += skew;
-			}
-		    }
-		}
-	    }
+	    if ( v < nvec )
+		store4_skewed(cfg, lds->slab, slab_cap, v << 2, head, buf[i]);
 	}
     }
 }
 
-// Correlate every bit window of candidates c_pos[0..nq) (all threads; one lane
-// per window, the twiddle index n is uniform so twiddles arrive through the
-// scalar cache).  The twiddle table is zero-padded to a multiple of XCH, so the
-// tail of the last chunk contributes fma(x, 0, acc) == acc; its sample index is
-// clamped so that it never touches unstaged LDS.
+// SCAN: correlate every bit window of candidates c_pos[0..nq) into mags[0]
 template <bool USE_SLAB>
 __device__ void par_correlate( const DevCfg &cfg, const double *__restrict__ tw, StreamLds *lds,
 	const float *__restrict__ x, uint32_t N, uint32_t row_org, uint32_t nq )
@@ -389,77 +477,36 @@ __device__ void par_correlate( const DevCfg &cfg, const double *__restrict__ tw,
 	const uint32_t q = active ? udiv_magic(w, n_bits, cfg.nbits_magic) : 0;
 	const uint32_t k = active ? w - q * n_bits : 0;
 	const uint32_t a = lds->c_pos[q] + cfg.bit_offset[k];
-	double mr = 0.0, mi = 0.0, sr = 0.0, si = 0.0;
+	double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
 	if ( USE_SLAB ) {
-	    uint32_t row, col;
-	    divmod_bit(cfg, a - row_org, row, col);
-	    const float *p = lds->slab + ( a - row_org ) + row * cfg.skew;
-	    const uint32_t last = B - 1;
-	    if ( __all(!active || col == 0u) ) {
-		// every window of this wave starts on a row boundary (the run-ahead
-		// frames of a locked carrier): plain immediate-offset reads
-		for ( uint32_t n0 = 0; n0 < B; n0 += XCH ) {
-		    float xs[XCH];
-#pragma unroll
-		    for ( int j = 0; j < XCH; j++ )
-			xs[j] = p[n0 + j < last ? n0 + j : last];
-		    const double *t = tw + 4 * (size_t)n0;
-#pragma unroll
-		    for ( int j = 0; j < XCH; j++ ) {
-			const double xd = (double)xs[j];
-			mr = fma(xd, t[4 * j + 0], mr);
-			mi = fma(xd, t[4 * j + 1], mi);
-			sr = fma(xd, t[4 * j + 2], sr);
-			si = fma(xd, t[4 * j + 3], si);
-		    }
-		}
-	    } else {
-		const uint32_t wrap = B - col;	// first n that falls into the next row
-		const uint32_t skew = cfg.skew;
-		for ( uint32_t n0 = 0; n0 < B; n0 += XCH ) {
-		    float xs[XCH];
-#pragma unroll
-		    for ( int j = 0; j < XCH; j++ ) {
-			const uint32_t n = n0 + j < last ? n0 + j : last;	// uniform
-			xs[j] = p[n + ( n >= wrap ? skew : 0u )];
-		    }
-		    const double *t = tw + 4 * (size_t)n0;
-#pragma unroll
-		    for ( int j = 0; j < XCH; j++ ) {
-			const double xd = (double)xs[j];
-			mr = fma(xd, t[4 * j + 0], mr);
-			mi = fma(xd, t[4 * j + 1], mi);
-			sr = fma(xd, t[4 * j + 2], sr);
-			si = fma(xd, t[4 * j + 3], si);
-		    }
-		}
-	    }
+	    correlate_window(cfg, tw, lds->slab, a - row_org, active, acc);
 	} else {
 	    for ( uint32_t n = 0; n < B; n++ ) {
 		const uint32_t idx = a + n;
 		const float xv = ( idx < N && idx >= a ) ? x[idx] : 0.0f;
 		const double xd = (double)xv;
 		const double *t = tw + 4 * (size_t)n;
-		mr = fma(xd, t[0], mr);
-		mi = fma(xd, t[1], mi);
-		sr = fma(xd, t[2], sr);
-		si = fma(xd, t[3], si);
+		acc[0] = fma(xd, t[0], acc[0]);
+		acc[1] = fma(xd, t[1], acc[1]);
+		acc[2] = fma(xd, t[2], acc[2]);
+		acc[3] = fma(xd, t[3], acc[3]);
 	    }
 	}
 	if ( active )
-	    lds->mags[w] = make_float2(band_mag(mr, mi, cfg.magscalar),
-				       band_mag(sr, si, cfg.magscalar));
+	    lds->mags[0][w] = make_float2(band_mag(acc[0], acc[1], cfg.magscalar),
+					  band_mag(acc[2], acc[3], cfg.magscalar));
     }
 }
 
-// what every wave does between "command published" and "correlated"
+// SCAN: what every wave does between "command published" and "correlated"
 template <bool USE_SLAB>
-__device__ __forceinline__ void parallel_part( const DevCfg &cfg, const double *__restrict__ tw,
-	StreamLds *lds, const float *__restrict__ x, uint32_t N, uint32_t slab_cap )
+__device__ __forceinline__ void scan_part( const DevCfg &cfg, const double *__restrict__ tw,
+	StreamLds *lds, const StreamLds::Cmd *cmd, const float *__restrict__ x, uint32_t N,
+	uint32_t slab_cap )
 {
-    const uint32_t nq = lds->cmd_nq;
-    const uint32_t row_org = lds->cmd_row_org;
-    if ( USE_SLAB && lds->cmd_stage ) {
+    const uint32_t nq = cmd->nq;
+    const uint32_t row_org = cmd->row_org;
+    if ( USE_SLAB && cmd->stage ) {
 	par_stage(cfg, lds, x, N, slab_cap, row_org);
 	__syncthreads();
     }
@@ -467,13 +514,85 @@ __device__ __forceinline__ void parallel_part( const DevCfg &cfg, const double *
     __syncthreads();
 }
 
-// LDS writes of this wave are visible to its other lanes in program order; this
-// only stops the compiler from moving accesses across the point
+// LDS accesses of one wave are executed in program order; this only stops the
+// compiler from moving them across the point
 __device__ __forceinline__ void wave_lds_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__device__ __forceinline__ uint32_t wave_min_u32( uint32_t v )
+{
+#pragma unroll
+    for ( int o = 32; o > 0; o >>= 1 ) {
+	const uint32_t t = (uint32_t)__shfl_xor((int)v, o);
+	v = t < v ? t : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_max_u32( uint32_t v )
+{
+#pragma unroll
+    for ( int o = 32; o > 0; o >>= 1 ) {
+	const uint32_t t = (uint32_t)__shfl_xor((int)v, o);
+	v = t > v ? t : v;
+    }
+    return v;
+}
+
+// LATTICE: one worker wave's share of a batch -- windows [64 wkr, 64 wkr + 64)
+// of frames anchor + f * lock_advance, f < frames.  The wave stages exactly the
+// samples its own windows cover into its private LDS region and correlates
+// them; there is no dependency on the other waves.
+__device__ void worker_lattice( const DevCfg &cfg, const double *__restrict__ tw, StreamLds *lds,
+	const StreamLds::Cmd *cmd, const float *__restrict__ x, uint32_t N,
+	uint32_t region_floats, uint32_t region_cap, uint32_t wkr )
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_bits = cfg.n_bits, B = cfg.bit_nsamples;
+    const uint32_t anchor = cmd->anchor;
+    const uint32_t nwin = cmd->frames * n_bits;
+    const uint32_t buf = cmd->buf;
+    const uint32_t w = wkr * 64u + lane;
+    if ( wkr * 64u >= nwin )
+	return;					// nothing for this wave (uniform)
+    const bool active = w < nwin;
+    const uint32_t wc = active ? w : nwin - 1u;	// idle lanes shadow the last window
+    const uint32_t f = udiv_magic(wc, n_bits, cfg.nbits_magic);
+    const uint32_t k = wc - f * n_bits;
+    const uint32_t a = anchor + f * cfg.lock_advance + cfg.bit_offset[k];
+    const uint32_t lo = wave_min_u32(a);
+    const uint32_t hi = wave_max_u32(a) + B;
+    float *region = lds->slab + (size_t)wkr * region_floats;
+
+    const uint32_t org4 = lo & ~3u;
+    const uint32_t head = lo - org4;
+    const uint32_t nvec = ( hi - org4 + 3 ) >> 2;
+    for ( uint32_t v0 = 0; v0 < nvec; v0 += 64 * STAGE_VEC ) {
+	float4 sbuf[STAGE_VEC];
+#pragma unroll
+	for ( int i = 0; i < STAGE_VEC; i++ ) {
+	    const uint32_t v = v0 + i * 64 + lane;
+	    sbuf[i] = v < nvec ? load4_guarded(x, org4 + ( v << 2 ), N)
+			       : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	}
+#pragma unroll
+	for ( int i = 0; i < STAGE_VEC; i++ ) {
+	    const uint32_t v = v0 + i * 64 + lane;
+	    if ( v < nvec )
+		store4_skewed(cfg, region, region_cap, v << 2, head, sbuf[i]);
+	}
+    }
+    wave_lds_sync();
+
+    double acc[4];
+    correlate_window(cfg, tw, region, a - lo, active, acc);
+    if ( active )
+	lds->mags[buf][w] = make_float2(band_mag(acc[0], acc[1], cfg.magscalar),
+					band_mag(acc[2], acc[3], cfg.magscalar));
 }
 
 template <bool USE_SLAB>
@@ -483,45 +602,122 @@ struct Master {
     const float		*x;		// this stream's samples
     uint32_t		N;		// valid samples; reads beyond see 0.0
     StreamLds		*lds;
-    uint32_t		slab_cap;	// samples the slab can hold
-    uint32_t		slab_lo, slab_hi;	// absolute range currently staged
-    uint32_t		npredict;	// frames to run ahead (0 = none)
+    uint32_t		slab_cap;	// SCAN: samples the whole slab can hold
+    uint32_t		slab_lo, slab_hi;	// SCAN: absolute range currently staged
+    uint32_t		lat_frames;	// LATTICE: frames per batch (0 = lattice off)
     uint32_t		lane;
+    // the lattice batch the workers are computing right now
+    bool		inflight;
+    uint32_t		inflight_anchor, inflight_frames, inflight_buf;
+    uint32_t		seq;		// barriers that published a command so far
     // work counters (written out only when the caller asked for them)
-    uint32_t		n_batches = 0, n_stages = 0, n_hits = 0, n_positions = 0;
-    uint64_t		cyc_par = 0, cyc_conf = 0;
+    uint32_t		n_batches = 0, n_stages = 0, n_hits = 0, n_positions = 0, n_lattice = 0;
+    uint64_t		cyc_par = 0, cyc_conf = 0, cyc_wait = 0;
 
     __device__ __forceinline__ Master( const DevCfg &c, const double *t, const float *xs,
-	    uint32_t n, StreamLds *l, uint32_t cap, uint32_t np )
+	    uint32_t n, StreamLds *l, uint32_t cap, uint32_t lf )
 	: cfg(c), tw(t), x(xs), N(n), lds(l), slab_cap(cap), slab_lo(0), slab_hi(0),
-	  npredict(np), lane(threadIdx.x) {}
+	  lat_frames(lf), lane(threadIdx.x), inflight(false), inflight_anchor(0),
+	  inflight_frames(0), inflight_buf(0), seq(0) {}
 
-    // Evaluate candidates c_pos[0..nq) (already in LDS) that span [lo, hi);
-    // row_org is where slab row 0 goes IF the slab has to be restaged.
-    __device__ void evaluate( uint32_t nq, uint32_t kind, uint32_t lo, uint32_t hi, uint32_t row_org )
+    // the slot for the command that the NEXT barrier publishes
+    __device__ __forceinline__ StreamLds::Cmd *next_cmd() { return &lds->cmd[seq & 1u]; }
+
+    // frames of a lattice batch anchored at `anchor` that still start inside the stream
+    __device__ __forceinline__ uint32_t lattice_frames_at( uint32_t anchor ) const
+    {
+	if ( anchor >= N )
+	    return 0;
+	const uint32_t left = udiv_magic(N - anchor - 1u, cfg.lock_advance, cfg.la_magic) + 1u;
+	return left < lat_frames ? left : lat_frames;
+    }
+
+    // publish a LATTICE (or IDLE) command; the caller then meets the barrier
+    __device__ __forceinline__ void publish_lattice( uint32_t anchor, uint32_t frames, uint32_t buf )
+    {
+	if ( lane == 0 ) {
+	    StreamLds::Cmd *c = next_cmd();
+	    c->op = frames ? CMD_LATTICE : CMD_IDLE;
+	    c->anchor = anchor;
+	    c->frames = frames;
+	    c->buf = buf;
+	}
+	inflight = frames != 0;
+	inflight_anchor = anchor;
+	inflight_frames = frames;
+	inflight_buf = buf;
+	slab_lo = slab_hi = 0;		// the regions overwrite whatever SCAN had staged
+    }
+
+    // Start the pipeline at `anchor` (nothing is in flight).
+    __device__ void lattice_start( uint32_t anchor )
+    {
+	const uint32_t frames = lattice_frames_at(anchor);
+	if ( !frames )
+	    return;
+	publish_lattice(anchor, frames, 0);
+	__syncthreads();			// workers pick the command up
+	seq++;
+    }
+
+    // The batch in flight is the one the cursor has reached: start the workers
+    // on the batch after it (speculatively) and score this one.
+    __device__ void lattice_advance()
+    {
+	const uint32_t anchor = inflight_anchor, frames = inflight_frames, buf = inflight_buf;
+	const uint32_t next = anchor + frames * cfg.lock_advance;
+	publish_lattice(next, lattice_frames_at(next), buf ^ 1u);
+	const uint64_t t_w = clock64();
+	__syncthreads();			// batch `anchor` is complete in mags[buf]
+	seq++;
+	const uint64_t t_c = clock64();
+	cyc_wait += t_c - t_w;
+	n_lattice++;
+	if ( lane < frames ) {
+	    const FrameOut fo = frame_confidence(&lds->mags[buf][lane * cfg.n_bits],
+						 cfg.expect[0], cfg.n_bits);
+	    lds->c_conf[lane] = fo.conf;
+	    lds->c_ampl[lane] = fo.ampl;
+	    lds->c_bits[lane] = fo.bits;
+	    lds->c_pos[lane] = anchor + lane * cfg.lock_advance;
+	}
+	if ( lane == 0 ) {
+	    lds->c_n = frames;
+	    lds->c_q = 0;
+	    lds->c_kind = 0;
+	}
+	wave_lds_sync();
+	cyc_conf += clock64() - t_c;
+    }
+
+    // SCAN: evaluate candidates c_pos[0..nq) (already in LDS) spanning [lo, hi)
+    __device__ void evaluate( uint32_t nq, uint32_t kind, uint32_t lo, uint32_t hi )
     {
 	bool restage = false;
 	if ( USE_SLAB && ( lo < slab_lo || hi > slab_hi ) ) {
 	    restage = true;
-	    slab_lo = row_org;
-	    slab_hi = row_org + slab_cap;
+	    slab_lo = lo;
+	    slab_hi = lo + slab_cap;
 	    n_stages++;
 	}
+	StreamLds::Cmd *c = next_cmd();
 	if ( lane == 0 ) {
-	    lds->cmd_op = 1;
-	    lds->cmd_nq = nq;
-	    lds->cmd_stage = restage ? 1u : 0u;
-	    lds->cmd_row_org = slab_lo;
+	    c->op = CMD_SCAN;
+	    c->nq = nq;
+	    c->stage = restage ? 1u : 0u;
+	    c->row_org = slab_lo;
 	}
+	inflight = false;		// the barrier below also retires any batch in flight
 	n_batches++;
 	n_positions += nq;
 	const uint64_t t_par = clock64();
 	__syncthreads();			// command (and c_pos[]) published
-	parallel_part<USE_SLAB>(cfg, tw, lds, x, N, slab_cap);
+	seq++;
+	scan_part<USE_SLAB>(cfg, tw, lds, c, x, N, slab_cap);
 	const uint64_t t_conf = clock64();
 	cyc_par += t_conf - t_par;
 	if ( lane < nq ) {
-	    const FrameOut f = frame_confidence(&lds->mags[lane * cfg.n_bits],
+	    const FrameOut f = frame_confidence(&lds->mags[0][lane * cfg.n_bits],
 						cfg.expect[kind], cfg.n_bits);
 	    lds->c_conf[lane] = f.conf;
 	    lds->c_ampl[lane] = f.ampl;
@@ -531,9 +727,9 @@ struct Master {
 	cyc_conf += clock64() - t_conf;
     }
 
-    // fsk_find_frame at cursor `base` (absolute), with run-ahead (see file header)
+    // fsk_find_frame at cursor `base` (absolute)
     __device__ ScanResult scan( uint32_t base, const ZigZag &zz, uint32_t first,
-	    float limit, uint32_t kind, bool may_predict )
+	    float limit, uint32_t kind )
     {
 	ScanResult r;
 	r.conf = 0.0f; r.ampl = 0.0f; r.bits = 0; r.start = 0;
@@ -571,42 +767,14 @@ struct Master {
 		tlo = t < tlo ? t : tlo;
 		thi = t > thi ? t : thi;
 	    }
-	    const uint32_t lo = base + tlo;
-	    uint32_t hi = base + thi + cfg.last_reach;
-	    // Row 0 of a restaged slab: on the bit grid of the first candidate,
-	    // so that the run-ahead windows (whole bits away from it) start on
-	    // row boundaries.
-	    uint32_t row_org = lo;
-	    if ( may_predict && p0 >= cfg.lock_back && p0 - cfg.lock_back <= lo
-		    && hi - ( p0 - cfg.lock_back ) <= slab_cap )
-		row_org = p0 - cfg.lock_back;
-	    // run-ahead: the next frames' first-try positions
-	    uint32_t M = 0;
-	    if ( may_predict && c0 == 0 && zz.J <= qmax ) {
-		M = qmax - Q < npredict ? qmax - Q : npredict;
-		if ( USE_SLAB ) {
-		    const uint32_t used = ( p0 - row_org ) + cfg.last_reach;
-		    const uint32_t fit = used < slab_cap ? udiv_magic(slab_cap - used, cfg.lock_advance, cfg.la_magic) : 0;
-		    M = M < fit ? M : fit;
-		}
-		// nothing to gain past the end of the stream
-		const uint32_t left = p0 < N ? udiv_magic(N - p0, cfg.lock_advance, cfg.la_magic) : 0;
-		M = M < left ? M : left;
-		if ( M ) {
-		    const uint32_t ph = p0 + M * cfg.lock_advance + cfg.last_reach;
-		    hi = ph > hi ? ph : hi;
-		}
-	    }
 	    if ( lane < Q )
 		lds->c_pos[lane] = base + zz.at(c0 + lane);
-	    else if ( lane < Q + M )
-		lds->c_pos[lane] = p0 + ( lane - Q + 1 ) * cfg.lock_advance;
 	    if ( lane == 0 ) {
-		lds->c_n = Q + M;
-		lds->c_q = Q;
+		lds->c_n = Q;
+		lds->c_q = Q;		// nothing here is a lattice frame
 		lds->c_kind = kind;
 	    }
-	    evaluate(Q + M, kind, lo, hi, row_org);
+	    evaluate(Q, kind, base + tlo, base + thi + cfg.last_reach);
 	    for ( uint32_t i = 0; i < Q; i++ ) {	// fsk.c:492-501
 		const float c = lds->c_conf[i];
 		if ( r.conf < c ) {
@@ -672,7 +840,7 @@ __device__ __forceinline__ float lane_bcast( float v, uint32_t src )
 // The reference's receive loop (minimodem.c:1137-1463); executed by wave 0 only.
 template <bool USE_SLAB>
 __device__ void master_loop( const DevCfg &cfg, const double *__restrict__ tw,
-	const mifsk_demod_io &io, uint32_t slab_cap, uint32_t npredict, StreamLds *lds )
+	const mifsk_demod_io &io, uint32_t slab_cap, uint32_t lat_frames, StreamLds *lds )
 {
     const uint32_t s = blockIdx.x;
     const float *x = io.d_samples + (size_t)s * io.stream_stride;
@@ -687,7 +855,7 @@ __device__ void master_loop( const DevCfg &cfg, const double *__restrict__ tw,
     const uint32_t lane = threadIdx.x;
     const bool t0 = lane == 0;
 
-    Master<USE_SLAB> ctx(cfg, tw, x, N, lds, slab_cap, npredict);
+    Master<USE_SLAB> ctx(cfg, tw, x, N, lds, slab_cap, lat_frames);
 
     // reference loop state (minimodem.c:1079-1088,1132-1133), uniform in the wave
     bool carrier = false;
@@ -712,13 +880,13 @@ __device__ void master_loop( const DevCfg &cfg, const double *__restrict__ tw,
 
     for (;;) {
 	// ------------------------------------------------------------------
-	// Bulk acceptance of run-ahead frames.  While carrier is held and the
-	// cursor lands where the run-ahead assumed, the reference's iteration
-	// for frame k reduces to: first try wins the coarse scan (c >= limit),
-	// no refine (c >= 0.75 peak), no squelch (a >= 0.25 track, c > thr).
-	// Those predicates and the f32 state recurrences are replayed here in
-	// frame order from the cached (confidence, amplitude) pairs; the first
-	// frame that fails any of them falls through to the general path below.
+	// Bulk acceptance of lattice frames.  While carrier is held and the
+	// cursor lands on the lattice, the reference's iteration for frame k
+	// reduces to: first try wins the coarse scan (c >= limit), no refine
+	// (c >= 0.75 peak), no squelch (a >= 0.25 track, c > threshold).  Those
+	// predicates and the f32 state recurrences are replayed here in frame
+	// order from the scored (confidence, amplitude) pairs; the first frame
+	// that fails any of them falls through to the general path below.
 	// ------------------------------------------------------------------
 	if ( carrier && advance && advance <= N - base ) {
 	    const uint64_t t_bulk = clock64();
@@ -728,6 +896,7 @@ __device__ void master_loop( const DevCfg &cfg, const double *__restrict__ tw,
 	    const uint32_t cn = lds->c_n, cq = lds->c_q;
 	    const bool m = lane >= cq && lane < cn && lds->c_kind == 0u && lds->c_pos[lane] == p;
 	    const unsigned long long bal = __ballot(m);
+	    bool progressed = false;
 	    if ( bal ) {
 		const uint32_t e0 = (uint32_t)__ffsll((long long)bal) - 1u;
 		uint32_t K = cn - e0;
@@ -825,9 +994,16 @@ __device__ void master_loop( const DevCfg &cfg, const double *__restrict__ tw,
 		    base = nb + ( n - 1u ) * la;
 		    advance = la;
 		    n_bulk += n;
+		    progressed = true;
 		}
+	    } else if ( ctx.inflight && ctx.inflight_anchor == p ) {
+		// the cursor has walked onto the batch the workers are finishing
+		ctx.lattice_advance();
+		progressed = true;
 	    }
 	    cyc_bulk += clock64() - t_bulk;
+	    if ( progressed )
+		continue;
 	}
 
 	// minimodem.c:1150-1156,1176,1229 under flat addressing
@@ -835,6 +1011,7 @@ __device__ void master_loop( const DevCfg &cfg, const double *__restrict__ tw,
 	    if ( advance > N - base )
 		break;
 	    base += advance;
+	    advance = 0;
 	}
 	const uint32_t avail = N - base;
 	if ( avail == 0 || avail < cfg.expect_nsamples )
@@ -847,7 +1024,7 @@ __device__ void master_loop( const DevCfg &cfg, const double *__restrict__ tw,
 	const uint32_t try_first = cfg.try_first[ci];
 
 	ScanResult sr = ctx.scan(base, carrier ? zc1 : zc0, try_first, cfg.search_limit,
-				 carrier ? 0u : 1u, carrier);	// minimodem.c:1265-1274
+				 carrier ? 0u : 1u);		// minimodem.c:1265-1274
 	float confidence = sr.conf;
 	float amplitude = sr.ampl;
 	uint64_t bits = sr.bits;
@@ -905,7 +1082,7 @@ __device__ void master_loop( const DevCfg &cfg, const double *__restrict__ tw,
 	if ( refine && confidence < INFINITY && try_step > 1u ) {	// minimodem.c:1357-1389
 	    // `carrier` is already set: an acquiring frame is re-searched with
 	    // the data string over the no-carrier range (minimodem.c:1378)
-	    ScanResult s2 = ctx.scan(base, ci ? zf1 : zf0, try_first, INFINITY, 0u, false);
+	    ScanResult s2 = ctx.scan(base, ci ? zf1 : zf0, try_first, INFINITY, 0u);
 	    flags |= MIFSK_FRAME_REFINED;
 	    n_refine++;
 	    if ( s2.conf > confidence ) {
@@ -951,6 +1128,17 @@ __device__ void master_loop( const DevCfg &cfg, const double *__restrict__ tw,
 	n_out_frames++;
 	if ( !suppressed )
 	    n_out_bytes++;
+
+	// carrier is held: (re)start the lattice pipeline where the next
+	// iteration will search first, unless a matching batch is already in
+	// flight or already scored
+	if ( ctx.lat_frames && advance <= N - base ) {
+	    const uint32_t p = base + advance + cfg.try_first[1];
+	    const bool cached = __ballot(lane >= lds->c_q && lane < lds->c_n
+					 && lds->c_kind == 0u && lds->c_pos[lane] == p) != 0ULL;
+	    if ( !cached && !( ctx.inflight && ctx.inflight_anchor == p ) )
+		ctx.lattice_start(p);
+	}
     }
 
     if ( carrier ) {						// minimodem.c:1469-1474
@@ -987,18 +1175,22 @@ __device__ void master_loop( const DevCfg &cfg, const double *__restrict__ tw,
 	    c[MIFSK_CNT_REFINES] = n_refine;
 	    c[MIFSK_CNT_CACHE_HITS] = ctx.n_hits;
 	    c[MIFSK_CNT_POSITIONS] = ctx.n_positions;
+	    c[MIFSK_CNT_LATTICE_BATCHES] = ctx.n_lattice;
 	    c[MIFSK_CNT_CYC_TOTAL] = clock64() - t_start;
 	    c[MIFSK_CNT_CYC_PARALLEL] = ctx.cyc_par;
+	    c[MIFSK_CNT_CYC_WAIT] = ctx.cyc_wait;
 	    c[MIFSK_CNT_CYC_CONFIDENCE] = ctx.cyc_conf;
 	    c[MIFSK_CNT_CYC_BULK] = cyc_bulk;
 	}
+	ctx.next_cmd()->op = CMD_EXIT;
     }
+    __syncthreads();				// releases the workers with "exit"
 }
 
 template <bool USE_SLAB>
 __global__ __launch_bounds__(BLOCK)
 void demod_kernel( DevCfg cfg, const double *__restrict__ tw, mifsk_demod_io io,
-	uint32_t slab_cap, uint32_t npredict )
+	uint32_t slab_cap, uint32_t lat_frames, uint32_t region_floats, uint32_t region_cap )
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     StreamLds *lds = reinterpret_cast<StreamLds *>(smem);
@@ -1007,7 +1199,6 @@ void demod_kernel( DevCfg cfg, const double *__restrict__ tw, mifsk_demod_io io,
 	lds->c_n = 0;
 	lds->c_q = 0;
 	lds->c_kind = 0;
-	lds->cmd_op = 1;
     }
     __syncthreads();
 
@@ -1015,19 +1206,22 @@ void demod_kernel( DevCfg cfg, const double *__restrict__ tw, mifsk_demod_io io,
 	// the serial chain is the critical path of the workgroup: let it win
 	// issue arbitration against the (throughput-bound) worker waves
 	__builtin_amdgcn_s_setprio(3);
-	master_loop<USE_SLAB>(cfg, tw, io, slab_cap, npredict, lds);
-	if ( threadIdx.x == 0 )
-	    lds->cmd_op = 0;
-	__syncthreads();			// releases the workers with "exit"
+	master_loop<USE_SLAB>(cfg, tw, io, slab_cap, lat_frames, lds);
     } else {
 	const uint32_t s = blockIdx.x;
 	const float *x = io.d_samples + (size_t)s * io.stream_stride;
 	const uint32_t N = io.d_nsamples ? io.d_nsamples[s] : io.nsamples;
-	for (;;) {
-	    __syncthreads();			// a command has been published
-	    if ( lds->cmd_op == 0 )
+	const uint32_t wkr = ( threadIdx.x >> 6 ) - 1u;
+	for ( uint32_t seq = 0; ; seq++ ) {
+	    __syncthreads();			// command number `seq` has been published
+	    const StreamLds::Cmd *cmd = &lds->cmd[seq & 1u];
+	    const uint32_t op = cmd->op;
+	    if ( op == CMD_EXIT )
 		break;
-	    parallel_part<USE_SLAB>(cfg, tw, lds, x, N, slab_cap);
+	    if ( op == CMD_SCAN )
+		scan_part<USE_SLAB>(cfg, tw, lds, cmd, x, N, slab_cap);
+	    else if ( USE_SLAB && op == CMD_LATTICE )
+		worker_lattice(cfg, tw, lds, cmd, x, N, region_floats, region_cap, wkr);
 	}
     }
 }
@@ -1091,42 +1285,58 @@ int launch_demod_batch( const DevCfg &cfg, const double *d_tw,
     // samples one search must see at once
     const uint32_t reach = ( cfg.try_max[0] > cfg.try_max[1] ? cfg.try_max[0] : cfg.try_max[1] )
 			 + cfg.last_reach + 8;
-    uint32_t qmax = W_CAP / cfg.n_bits;
-    if ( qmax > P_CAP ) qmax = P_CAP;
-    // run-ahead depth: fill one pass of BLOCK lanes with bit windows
-    uint32_t coarse_j = 3;	// typical carrier coarse scan (first, +step, -step)
-    uint32_t want = BLOCK / cfg.n_bits > coarse_j ? BLOCK / cfg.n_bits - coarse_j : 0;
-    if ( want > qmax - coarse_j ) want = qmax > coarse_j ? qmax - coarse_j : 0;
-
+    auto floats_for = [&]( uint32_t nsamp ) -> size_t {
+	return ( (size_t)nsamp + (size_t)( nsamp / B + 2 ) * cfg.skew + 8 + 3 ) & ~(size_t)3;
+    };
     // LDS budget: 4 workgroups per CU when the stream count can use them
     const size_t budget_small = kLdsPerCu / 4 - 64;
-    auto floats_for = [&]( uint32_t nsamp ) -> size_t {
-	return (size_t)nsamp + (size_t)( nsamp / B + 1 ) * cfg.skew + 8;
-    };
-    auto samples_in = [&]( size_t bytes ) -> uint32_t {
-	if ( bytes <= kLdsHeader + 64 ) return 0;
-	size_t fl = ( bytes - kLdsHeader ) / 4;
-	size_t ns = fl * B / ( B + cfg.skew );
-	ns = ns > 16 ? ns - 16 : 0;
-	return (uint32_t)( ns & ~(size_t)3 );
-    };
 
-    uint32_t slab_cap = 0, npredict = 0;
+    // LATTICE geometry: `frames` per batch so that the windows fill the worker
+    // lanes; each worker wave's region must hold the samples its 64 windows span
+    auto region_samples = [&]( uint32_t frames ) -> uint32_t {
+	const uint32_t nwin = frames * cfg.n_bits;
+	uint32_t worst = 0;
+	for ( uint32_t w0 = 0; w0 < nwin; w0 += 64 ) {
+	    uint32_t lo = 0xFFFFFFFFu, hi = 0;
+	    for ( uint32_t w = w0; w < w0 + 64 && w < nwin; w++ ) {
+		const uint32_t a = ( w / cfg.n_bits ) * cfg.lock_advance + cfg.bit_offset[w % cfg.n_bits];
+		lo = a < lo ? a : lo;
+		hi = a + B > hi ? a + B : hi;
+	    }
+	    worst = hi - lo > worst ? hi - lo : worst;
+	}
+	return ( worst + 4 + 3 ) & ~3u;		// + up to 3 samples of alignment head
+    };
+    uint32_t lat_frames = LAT_LANES / cfg.n_bits;
+    if ( lat_frames > P_CAP ) lat_frames = P_CAP;
+    uint32_t region_cap = 0;
+    size_t region_floats = 0;
+    while ( lat_frames ) {
+	region_cap = region_samples(lat_frames);
+	region_floats = floats_for(region_cap);
+	if ( kLdsHeader + NWORKERS * region_floats * 4 <= budget_small
+		&& NWORKERS * region_floats >= floats_for(reach + 4) )
+	    break;
+	lat_frames--;
+    }
+
+    uint32_t slab_cap = 0;
+    size_t slab_floats = 0;
     bool use_slab = true;
-    const uint32_t ideal = reach + want * cfg.lock_advance + B;
-    if ( kLdsHeader + floats_for(ideal) * 4 <= budget_small ) {
-	slab_cap = ( ideal + 3 ) & ~3u;
-	npredict = want;
-    } else if ( samples_in(budget_small) >= reach + cfg.lock_advance ) {
-	slab_cap = samples_in(budget_small);
-	npredict = ( slab_cap - reach ) / cfg.lock_advance;
-	if ( npredict > want ) npredict = want;
+    if ( lat_frames ) {
+	slab_floats = NWORKERS * region_floats;
+	// samples the whole slab holds in SCAN mode
+	size_t ns = slab_floats * B / ( B + cfg.skew );
+	ns = ns > 16 ? ns - 16 : 0;
+	slab_cap = (uint32_t)( ns & ~(size_t)3 );
     } else {
-	// long bit windows: take as much LDS as one search needs (fewer WGs/CU)
+	// long bit windows: no lattice; take as much LDS as one search needs
+	region_cap = 0;
+	region_floats = 0;
 	const size_t need = kLdsHeader + floats_for(reach + 4) * 4;
 	if ( need <= kLdsPerCu - 1024 ) {
 	    slab_cap = ( reach + 4 + 3 ) & ~3u;
-	    npredict = 0;
+	    slab_floats = floats_for(slab_cap);
 	} else {
 	    use_slab = false;	// e.g. 0.5 baud: windows of 96000 samples
 	}
@@ -1134,17 +1344,18 @@ int launch_demod_batch( const DevCfg &cfg, const double *d_tw,
 
     hipStream_t st = (hipStream_t)stream;
     if ( use_slab ) {
-	const size_t lds_bytes = kLdsHeader + floats_for(slab_cap) * 4;
+	const size_t lds_bytes = kLdsHeader + slab_floats * 4;
 	hipError_t e = hipFuncSetAttribute(
 		reinterpret_cast<const void *>(&demod_kernel<true>),
 		hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 	if ( e != hipSuccess )
 	    return hip_rc(e);
 	hipLaunchKernelGGL(demod_kernel<true>, dim3((unsigned)io.nstreams), dim3(BLOCK),
-			   lds_bytes, st, cfg, d_tw, io, slab_cap, npredict);
+			   lds_bytes, st, cfg, d_tw, io, slab_cap, lat_frames,
+			   (uint32_t)region_floats, region_cap);
     } else {
 	hipLaunchKernelGGL(demod_kernel<false>, dim3((unsigned)io.nstreams), dim3(BLOCK),
-			   kLdsHeader + 16, st, cfg, d_tw, io, 0u, 0u);
+			   kLdsHeader + 16, st, cfg, d_tw, io, 0u, 0u, 0u, 0u);
     }
     return hip_rc(hipGetLastError());
 }
