@@ -37,7 +37,8 @@ assert SEARCH_DTYPE.itemsize == 32 and RESULT_DTYPE.itemsize == 24
 NCOUNTERS = 16
 COUNTER_NAMES = {0: "iterations", 1: "batches", 2: "stages", 3: "bulk_frames", 4: "refines",
                  5: "cache_hits", 6: "positions", 7: "lattice_batches", 8: "cyc_total",
-                 9: "cyc_scan", 10: "cyc_wait", 11: "cyc_confidence", 12: "cyc_bulk"}
+                 9: "cyc_scan", 10: "cyc_wait", 11: "cyc_confidence", 12: "cyc_bulk", 13: "w_stage", 14: "w_correlate",
+                 15: "w_barrier"}
 
 
 def build(force=False):

@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmifsk.so")
+# MIFSK_LIBRARY selects another build of the same library (e.g. libmifsk_prof.so)
+LIB_PATH = os.environ.get("MIFSK_LIBRARY") or os.path.join(_HERE, "libmifsk.so")
 MAX_BITS = 64
 
 

@@ -69,11 +69,22 @@ void fill_devcfg( DevCfg &d, const mifsk_rx_config &c )
 	}
 	d.lock_back = ( down + c.bit_nsamples - 1 ) / c.bit_nsamples * c.bit_nsamples;
     }
+    // every lattice window starts a multiple of 4 samples after the first one
+    // when the bit length, all bit offsets and the frame step are multiples of
+    // 4: then an unskewed region read with 16-byte LDS loads is conflict-light
+    d.lat_linear = ( c.bit_nsamples % 4 == 0 && d.lock_advance % 4 == 0 ) ? 1u : 0u;
+    for ( unsigned k = 0; k < c.expect_n_bits; k++ )
+	if ( c.bit_offset[k] % 4 != 0 )
+	    d.lat_linear = 0;
     for ( unsigned k = 0; k < c.expect_n_bits; k++ ) {
 	d.bit_offset[k] = c.bit_offset[k];
 	for ( int s = 0; s < 2; s++ ) {
 	    const char ch = ( s ? c.expect_sync : c.expect_data )[k];
-	    d.expect[s][k] = ch == 'd' ? 2 : (uint8_t)( ch - '0' );
+	    if ( ch != 'd' ) {
+		d.req_mask[s] |= 1ULL << k;
+		if ( ch == '1' )
+		    d.req_val[s] |= 1ULL << k;
+	    }
 	}
     }
 }
@@ -100,11 +111,18 @@ struct TwEntry {
     double	*d_tw;
 };
 
+// device-resident copies of the kernel configuration, one per distinct config
+struct CfgEntry {
+    DevCfg	host;
+    DevCfg	*dev;
+};
+
 struct mifsk_ctx {
     int			device;
     char		name[256];
     std::mutex		lock;
     std::vector<TwEntry>	tables;
+    std::vector<CfgEntry>	configs;
     // spectrum table for fsk_detect_carrier
     unsigned		cs_fftsize;
     double		*d_cs;
@@ -157,6 +175,8 @@ extern "C" void mifsk_ctx_destroy( mifsk_ctx *ctx )
 	return;
     for ( TwEntry &e : ctx->tables )
 	(void)hipFree(e.d_tw);
+    for ( CfgEntry &e : ctx->configs )
+	(void)hipFree(e.dev);
     if ( ctx->d_cs )
 	(void)hipFree(ctx->d_cs);
     delete ctx;
@@ -200,6 +220,27 @@ static int get_twiddles( mifsk_ctx *ctx, const TwKey &key, const double **d_out 
     return 0;
 }
 
+static int get_devcfg( mifsk_ctx *ctx, const DevCfg &d, const DevCfg **d_out )
+{
+    std::lock_guard<std::mutex> g(ctx->lock);
+    for ( const CfgEntry &e : ctx->configs )
+	if ( std::memcmp(&e.host, &d, sizeof(DevCfg)) == 0 ) {
+	    *d_out = e.dev;
+	    return 0;
+	}
+    if ( ctx->configs.size() >= 64 ) {		// bounded cache (legacy API makes one per window shape)
+	for ( CfgEntry &e : ctx->configs )
+	    (void)hipFree(e.dev);
+	ctx->configs.clear();
+    }
+    DevCfg *dev = nullptr;
+    HIP_OK(hipMalloc(&dev, sizeof(DevCfg)));
+    HIP_OK(hipMemcpy(dev, &d, sizeof(DevCfg), hipMemcpyHostToDevice));
+    ctx->configs.push_back(CfgEntry{d, dev});
+    *d_out = dev;
+    return 0;
+}
+
 static int check_cfg( const mifsk_rx_config *cfg )
 {
     if ( !cfg || cfg->expect_n_bits == 0 || cfg->expect_n_bits > MIFSK_MAX_FRAME_BITS
@@ -226,7 +267,11 @@ extern "C" int mifsk_find_frame_batch( mifsk_ctx *ctx, const mifsk_rx_config *cf
 	return rc;
     DevCfg d;
     mifsk::fill_devcfg(d, *cfg);
-    return mifsk::launch_find_frame_batch(d, d_tw, d_samples, d_problems, d_results,
+    const DevCfg *d_cfg = nullptr;
+    rc = get_devcfg(ctx, d, &d_cfg);
+    if ( rc )
+	return rc;
+    return mifsk::launch_find_frame_batch(d, d_cfg, d_tw, d_samples, d_problems, d_results,
 					  nproblems, stream);
 }
 
@@ -251,7 +296,11 @@ extern "C" int mifsk_demod_batch( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
 	return rc;
     DevCfg d;
     mifsk::fill_devcfg(d, *cfg);
-    return mifsk::launch_demod_batch(d, d_tw, *io, stream);
+    const DevCfg *d_cfg = nullptr;
+    rc = get_devcfg(ctx, d, &d_cfg);
+    if ( rc )
+	return rc;
+    return mifsk::launch_demod_batch(d, d_cfg, d_tw, *io, stream);
 }
 
 namespace {

@@ -34,8 +34,13 @@ struct DevCfg {
     uint32_t	la_magic;		// floor(2^32 / lock_advance)
     uint32_t	nbits_magic;		// floor(2^32 / n_bits)
     uint32_t	lock_back;		// slab row 0 sits this far before a locked frame's first try
+    uint32_t	lat_linear;		// lattice windows all start on 16-byte boundaries of their region
+    uint32_t	pad1;
     uint32_t	bit_offset[MIFSK_MAX_FRAME_BITS];	// fsk.c:204
-    uint8_t	expect[2][MIFSK_MAX_FRAME_BITS];	// [0]=data [1]=sync; 0,1 or 2 ('d')
+    // expect strings as bit masks, [0]=data [1]=sync: bit k of req_mask is set
+    // when bit k of the frame is required ('0'/'1'), req_val holds its value
+    uint64_t	req_mask[2];
+    uint64_t	req_val[2];
 };
 
 // twiddles: tw[4*n + {0,1,2,3}] = cos_mark, -sin_mark, cos_space, -sin_space
@@ -44,11 +49,11 @@ struct DevCfg {
 void fill_devcfg( DevCfg &d, const mifsk_rx_config &c );
 
 // launchers (mifsk_kernels.hip); `stream` is a hipStream_t
-int launch_find_frame_batch( const DevCfg &cfg, const double *d_tw,
+int launch_find_frame_batch( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_tw,
 	const float *d_samples, const mifsk_search *d_problems,
 	mifsk_search_result *d_results, int nproblems, void *stream );
 
-int launch_demod_batch( const DevCfg &cfg, const double *d_tw,
+int launch_demod_batch( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_tw,
 	const mifsk_demod_io &io, void *stream );
 
 int launch_detect_carrier( const float *d_samples, unsigned nsamples,

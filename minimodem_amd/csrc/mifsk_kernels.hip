@@ -33,6 +33,17 @@
 
 #include "mifsk_device.h"
 
+// cycle timers for tools/counters.py; off in the production build because
+// each s_memtime read costs the serial wave a round trip
+#ifndef MIFSK_ABL
+#define MIFSK_ABL 0
+#endif
+#ifdef MIFSK_PROFILE
+#define MIFSK_CLOCK() clock64()
+#else
+#define MIFSK_CLOCK() 0ULL
+#endif
+
 namespace mifsk {
 
 constexpr int BLOCK = 256;	// threads per stream workgroup (4 waves)
@@ -49,6 +60,14 @@ constexpr int W_CAP = 256;	// bit windows per batch (LDS scratch)
 // host, tests/test_host_math.py); f64 sqrt on gfx950 is correctly rounded.
 __device__ __forceinline__ float band_mag( double re, double im, float scalar )
 {
+#if MIFSK_ABL == 1
+    {	// additive ablation: the same work once more, result kept alive but unused
+	const float fr2 = (float)( re * 1.0000001 ), fi2 = (float)im;
+	const double s2 = (double)fr2 * (double)fr2 + (double)fi2 * (double)fi2;
+	float dummy = (float)sqrt(s2) * scalar;
+	asm volatile("" :: "v"(dummy));
+    }
+#endif
     const float fr = (float)re, fi = (float)im;
     const double s = (double)fr * (double)fr + (double)fi * (double)fi;
     return (float)sqrt(s) * scalar;
@@ -63,9 +82,13 @@ struct FrameOut {
 // fsk_frame_analyze after the per-bit magnitudes are known (fsk.c:199-212,
 // 271-342, 439-441).  `mags[k]` = (mark, space) magnitude of bit k.  One lane
 // runs this for one candidate position; every operation is f32, in the
-// reference's order (contraction is disabled for this file).
+// reference's order (contraction is disabled for this file).  The magnitudes
+// are fetched from LDS eight at a time so that the loads (and, in the second
+// pass, the independent divisions) overlap; the running sums stay sequential.
+constexpr int CCH = 8;
+
 __device__ __forceinline__ FrameOut
-frame_confidence( const float2 *mags, const uint8_t *expect, uint32_t n_bits )
+frame_confidence( const float2 *mags, uint64_t req_mask, uint64_t req_val, uint32_t n_bits )
 {
     FrameOut out;
     out.conf = 0.0f;
@@ -75,31 +98,37 @@ frame_confidence( const float2 *mags, const uint8_t *expect, uint32_t n_bits )
     uint64_t bits = 0;
     float total_sig = 0.0f, total_noise = 0.0f;
     float mark_sig = 0.0f, space_sig = 0.0f;
-    uint32_t n_mark = 0, n_space = 0;
-    bool mismatch = false;
-#pragma unroll 4
-    for ( uint32_t k = 0; k < n_bits; k++ ) {
-	const float2 m = mags[k];
-	const bool one = m.x > m.y;			// fsk.c:161 (strict)
-	const float sig = one ? m.x : m.y;
-	const float noise = one ? m.y : m.x;
-	const uint32_t e = expect[k];
-	if ( e != 2u && e != (one ? 1u : 0u) )
-	    mismatch = true;				// fsk.c:211-212
-	bits |= (uint64_t)(one ? 1u : 0u) << k;
-	total_sig += sig;				// fsk.c:278
-	if ( noise > FLT_EPSILON )			// fsk.c:279
-	    total_noise += noise;
-	if ( one ) {
-	    mark_sig += sig;
-	    n_mark++;
-	} else {
-	    space_sig += sig;
-	    n_space++;
+    uint32_t n_mark = 0;
+    const uint32_t last = n_bits - 1u;
+    for ( uint32_t k0 = 0; k0 < n_bits; k0 += CCH ) {
+	float2 m[CCH];
+#pragma unroll
+	for ( int j = 0; j < CCH; j++ )
+	    m[j] = mags[k0 + j < last ? k0 + j : last];
+#pragma unroll
+	for ( int j = 0; j < CCH; j++ ) {
+	    if ( k0 + j < n_bits ) {
+		const bool one = m[j].x > m[j].y;		// fsk.c:161 (strict)
+		const float sig = one ? m[j].x : m[j].y;
+		const float noise = one ? m[j].y : m[j].x;
+		bits |= (uint64_t)( one ? 1u : 0u ) << ( k0 + j );
+		total_sig += sig;				// fsk.c:278
+		if ( noise > FLT_EPSILON )			// fsk.c:279
+		    total_noise += noise;
+		if ( one ) {
+		    mark_sig += sig;
+		    n_mark++;
+		} else {
+		    space_sig += sig;
+		}
+	    }
 	}
     }
-    if ( mismatch )
-	return out;		// confidence 0, bits/ampl stay 0 (fsk.c:486-487)
+    // a required bit that came out wrong rejects the frame with confidence 0
+    // and bits/ampl untouched (fsk.c:211-212,486-487)
+    if ( ( bits ^ req_val ) & req_mask )
+	return out;
+    const uint32_t n_space = n_bits - n_mark;
 
     const float snr = total_sig / total_noise;		// fsk.c:292
     const float avg_sig = total_sig / (float)(int)n_bits;	// fsk.c:295 (int n_bits)
@@ -109,13 +138,20 @@ frame_confidence( const float2 *mags, const uint8_t *expect, uint32_t n_bits )
 	space_sig /= (float)n_space;
 
     float divergence = 0.0f;				// fsk.c:305-313
-#pragma unroll 4
-    for ( uint32_t k = 0; k < n_bits; k++ ) {
-	const float2 m = mags[k];
-	const bool one = m.x > m.y;
-	const float sig = one ? m.x : m.y;
-	const float cls = one ? mark_sig : space_sig;
-	divergence += fabsf(sig - cls) / cls;
+    for ( uint32_t k0 = 0; k0 < n_bits; k0 += CCH ) {
+	float term[CCH];
+#pragma unroll
+	for ( int j = 0; j < CCH; j++ ) {
+	    const float2 m = mags[k0 + j < last ? k0 + j : last];
+	    const bool one = m.x > m.y;
+	    const float sig = one ? m.x : m.y;
+	    const float cls = one ? mark_sig : space_sig;
+	    term[j] = fabsf(sig - cls) / cls;
+	}
+#pragma unroll
+	for ( int j = 0; j < CCH; j++ )
+	    if ( k0 + j < n_bits )
+		divergence += term[j];
     }
     divergence *= 2.0f;
     divergence /= (float)(int)n_bits;
@@ -165,7 +201,7 @@ struct ZigZag {
 // ---------------------------------------------------------------------------
 
 __global__ __launch_bounds__(64)
-void find_frame_kernel( DevCfg cfg, const double *__restrict__ tw,
+void find_frame_kernel( const DevCfg *__restrict__ cfgp, const double *__restrict__ tw,
 	const float *__restrict__ samples, const mifsk_search *__restrict__ problems,
 	mifsk_search_result *__restrict__ results )
 {
@@ -174,12 +210,13 @@ void find_frame_kernel( DevCfg cfg, const double *__restrict__ tw,
     __shared__ float s_ampl[P_CAP];
     __shared__ uint64_t s_bits[P_CAP];
 
+    const DevCfg &cfg = *cfgp;
     const mifsk_search pr = problems[blockIdx.x];
     const float *x = samples + pr.sample_offset;
     const uint32_t navail = pr.navail;
     const uint32_t n_bits = cfg.n_bits;
     const uint32_t B = cfg.bit_nsamples;
-    const uint8_t *expect = cfg.expect[pr.use_sync_string ? 1 : 0];
+    const uint32_t ek = pr.use_sync_string ? 1u : 0u;
     const uint32_t lane = threadIdx.x;
 
     const ZigZag zz(pr.try_first, pr.try_max, pr.try_step);
@@ -217,7 +254,8 @@ void find_frame_kernel( DevCfg cfg, const double *__restrict__ tw,
 	}
 	__syncthreads();
 	if ( lane < Q ) {
-	    const FrameOut f = frame_confidence(&s_mags[lane * n_bits], expect, n_bits);
+	    const FrameOut f = frame_confidence(&s_mags[lane * n_bits], cfg.req_mask[ek],
+						cfg.req_val[ek], n_bits);
 	    s_conf[lane] = f.conf;
 	    s_ampl[lane] = f.ampl;
 	    s_bits[lane] = f.bits;
@@ -339,34 +377,55 @@ __device__ __forceinline__ uint32_t udiv_magic( uint32_t x, uint32_t d, uint32_t
     return q;
 }
 
-__device__ __forceinline__ float4 load4_guarded( const float *__restrict__ x, uint32_t a, uint32_t N )
+// One aligned float4 of the stream at sample index a (a % 4 == 0), RAW: the
+// address is clamped into the row and nothing is done with the data, so that a
+// run of these loads is issued back to back and stays in flight together (any
+// branch or select on the loaded value makes the compiler drain vmcnt per
+// load).  Rows are padded to whole float4s (stream_stride % 4 == 0 and
+// N <= stream_stride), so the access is always inside the row.
+__device__ __forceinline__ float4 load4_raw( const float *__restrict__ x, uint32_t a, uint32_t N )
 {
-    float4 s;
-    if ( a + 3 < N && a + 3 >= a ) {
-	s = *reinterpret_cast<const float4 *>(x + a);	// 16 B per lane, coalesced
-    } else {
-	s.x = a < N ? x[a] : 0.0f;
-	s.y = ( a + 1 < N && a + 1 > a ) ? x[a + 1] : 0.0f;
-	s.z = ( a + 2 < N && a + 2 > a ) ? x[a + 2] : 0.0f;
-	s.w = ( a + 3 < N && a + 3 > a ) ? x[a + 3] : 0.0f;
-    }
+    const uint32_t aa = a < N ? a : 0u;
+    return *reinterpret_cast<const float4 *>(x + aa);	// 16 B per lane, coalesced
+}
+
+// ... and the masking that goes with it, applied when the data is consumed:
+// samples at or beyond N read as 0.0
+__device__ __forceinline__ float4 mask4( float4 s, uint32_t a, uint32_t N )
+{
+    s.x = a < N ? s.x : 0.0f;
+    s.y = ( a < N && a + 1 < N ) ? s.y : 0.0f;
+    s.z = ( a < N && a + 2 < N ) ? s.z : 0.0f;
+    s.w = ( a < N && a + 3 < N ) ? s.w : 0.0f;
     return s;
 }
 
-// Write the 4 samples of the float4 that sits `first` samples after org4 into a
-// skewed slab whose row 0 starts `head` samples after org4.  The LDS word of
-// slab-relative sample rel is rel + (rel / B) * skew: rows of one bit length
-// with `skew` pad words in between, so lanes whose windows start a whole number
-// of bits apart read different banks.
+// Write the float4 loaded from stream index a = org4 + first into a skewed slab
+// whose row 0 starts `head` samples after org4 (`first` = offset from org4).
+// The LDS word of slab-relative sample rel is rel + (rel / B) * skew: rows of
+// one bit length with `skew` pad words in between, so lanes whose windows start
+// a whole number of bits apart read different banks.  Samples at or beyond N
+// are written as 0.0; samples before row 0 or past `cap` are dropped.
 __device__ __forceinline__ void store4_skewed( const DevCfg &cfg, float *slab, uint32_t cap,
-	uint32_t first, uint32_t head, const float4 &s )
+	uint32_t first, uint32_t head, float4 s, uint32_t a, uint32_t N )
 {
     const uint32_t B = cfg.bit_nsamples, skew = cfg.skew;
-    const float e[4] = { s.x, s.y, s.z, s.w };
     const uint32_t rel0 = first >= head ? first - head : 0u;
     uint32_t q, r;
     divmod_bit(cfg, rel0, q, r);
-    uint32_t idx = rel0 + q * skew;
+    const uint32_t idx0 = rel0 + q * skew;
+    if ( first >= head && rel0 + 3 < cap && a + 3 < N && a + 3 >= a && B >= 4 ) {
+	// common case: four in-range samples, at most one row boundary inside
+	float *d = slab + idx0;
+	d[0] = s.x;
+	d[1 + ( r + 1 >= B ? skew : 0u )] = s.y;
+	d[2 + ( r + 2 >= B ? skew : 0u )] = s.z;
+	d[3 + ( r + 3 >= B ? skew : 0u )] = s.w;
+	return;
+    }
+    s = mask4(s, a, N);
+    const float e[4] = { s.x, s.y, s.z, s.w };
+    uint32_t idx = idx0;
 #pragma unroll
     for ( int j = 0; j < 4; j++ ) {
 	const uint32_t rel = first + j - head;		// meaningful when first + j >= head
@@ -381,12 +440,50 @@ __device__ __forceinline__ void store4_skewed( const DevCfg &cfg, float *slab, u
     }
 }
 
+extern __shared__ __attribute__((aligned(16))) unsigned char mifsk_smem[];
+
+// Twiddles of XCH = 8 consecutive samples (8 x 4 doubles = 64 SGPRs), fetched
+// through the scalar cache with all four loads in flight at once.  Inline asm
+// because the register allocator, left to itself in this large kernel, issues
+// them one at a time (load 16 SGPRs, wait, 8 FMAs, ...), which exposes the
+// scalar-memory latency four times per chunk.  The caller must execute
+// twiddle_wait() before touching the values.
+typedef double tw8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void twiddle_fetch( const double *t, tw8 &a, tw8 &b, tw8 &c, tw8 &d )
+{
+    asm volatile("s_load_dwordx16 %0, %4, 0x0\n\t"
+		 "s_load_dwordx16 %1, %4, 0x40\n\t"
+		 "s_load_dwordx16 %2, %4, 0x80\n\t"
+		 "s_load_dwordx16 %3, %4, 0xc0"
+		 : "=&s"(a), "=&s"(b), "=&s"(c), "=&s"(d)
+		 : "s"(t)
+		 : "memory");
+}
+
+__device__ __forceinline__ void twiddle_wait()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+#define MIFSK_FMA4(X, T, I)					\
+    do {							\
+	const double xd_ = (double)(X);				\
+	mr = fma(xd_, (T)[4 * (I) + 0], mr);			\
+	mi = fma(xd_, (T)[4 * (I) + 1], mi);			\
+	sr = fma(xd_, (T)[4 * (I) + 2], sr);			\
+	si = fma(xd_, (T)[4 * (I) + 3], si);			\
+    } while (0)
+
 // The two-band correlation of ONE bit window held in a skewed slab (one lane).
 // `rel` is the window start relative to slab row 0.  The twiddle index is
 // uniform across the wave, so the twiddles arrive through the scalar cache; the
 // table is zero-padded to a multiple of XCH and the tail of the last chunk
 // contributes fma(x, 0, acc) == acc (its sample index is clamped so that it
 // never reads LDS that was not staged).
+static_assert(XCH == 8, "twiddle_fetch moves exactly 8 samples' worth");
+
 __device__ __forceinline__ void correlate_window( const DevCfg &cfg, const double *__restrict__ tw,
 	const float *slab, uint32_t rel, bool active, double acc[4] )
 {
@@ -400,46 +497,42 @@ __device__ __forceinline__ void correlate_window( const DevCfg &cfg, const doubl
 	// every window of this wave starts on a row boundary: plain
 	// immediate-offset LDS reads, no per-sample address arithmetic
 	for ( uint32_t n0 = 0; n0 < B; n0 += XCH ) {
+	    tw8 ta, tb, tc, td;
+	    twiddle_fetch(tw + 4 * (size_t)n0, ta, tb, tc, td);
 	    float xs[XCH];
 #pragma unroll
 	    for ( int j = 0; j < XCH; j++ )
 		xs[j] = p[n0 + j < last ? n0 + j : last];
-	    const double *t = tw + 4 * (size_t)n0;
-#pragma unroll
-	    for ( int j = 0; j < XCH; j++ ) {
-		const double xd = (double)xs[j];
-		mr = fma(xd, t[4 * j + 0], mr);
-		mi = fma(xd, t[4 * j + 1], mi);
-		sr = fma(xd, t[4 * j + 2], sr);
-		si = fma(xd, t[4 * j + 3], si);
-	    }
+	    twiddle_wait();
+	    MIFSK_FMA4(xs[0], ta, 0);  MIFSK_FMA4(xs[1], ta, 1);
+	    MIFSK_FMA4(xs[2], tb, 0);  MIFSK_FMA4(xs[3], tb, 1);
+	    MIFSK_FMA4(xs[4], tc, 0);  MIFSK_FMA4(xs[5], tc, 1);
+	    MIFSK_FMA4(xs[6], td, 0);  MIFSK_FMA4(xs[7], td, 1);
 	}
     } else {
 	const uint32_t wrap = B - col;	// first n that falls into the next row
 	const uint32_t skew = cfg.skew;
 	for ( uint32_t n0 = 0; n0 < B; n0 += XCH ) {
+	    tw8 ta, tb, tc, td;
+	    twiddle_fetch(tw + 4 * (size_t)n0, ta, tb, tc, td);
 	    float xs[XCH];
 #pragma unroll
 	    for ( int j = 0; j < XCH; j++ ) {
 		const uint32_t n = n0 + j < last ? n0 + j : last;	// uniform
 		xs[j] = p[n + ( n >= wrap ? skew : 0u )];
 	    }
-	    const double *t = tw + 4 * (size_t)n0;
-#pragma unroll
-	    for ( int j = 0; j < XCH; j++ ) {
-		const double xd = (double)xs[j];
-		mr = fma(xd, t[4 * j + 0], mr);
-		mi = fma(xd, t[4 * j + 1], mi);
-		sr = fma(xd, t[4 * j + 2], sr);
-		si = fma(xd, t[4 * j + 3], si);
-	    }
+	    twiddle_wait();
+	    MIFSK_FMA4(xs[0], ta, 0);  MIFSK_FMA4(xs[1], ta, 1);
+	    MIFSK_FMA4(xs[2], tb, 0);  MIFSK_FMA4(xs[3], tb, 1);
+	    MIFSK_FMA4(xs[4], tc, 0);  MIFSK_FMA4(xs[5], tc, 1);
+	    MIFSK_FMA4(xs[6], td, 0);  MIFSK_FMA4(xs[7], td, 1);
 	}
     }
     acc[0] = mr; acc[1] = mi; acc[2] = sr; acc[3] = si;
 }
 
 // SCAN: stage samples [row_org, row_org + slab_cap) into the slab (all threads)
-__device__ void par_stage( const DevCfg &cfg, StreamLds *lds, const float *__restrict__ x,
+__device__ __forceinline__ void par_stage( const DevCfg &cfg, StreamLds *lds, const float *__restrict__ x,
 	uint32_t N, uint32_t slab_cap, uint32_t row_org )
 {
     const uint32_t org4 = row_org & ~3u;
@@ -451,21 +544,20 @@ __device__ void par_stage( const DevCfg &cfg, StreamLds *lds, const float *__res
 #pragma unroll
 	for ( int i = 0; i < STAGE_VEC; i++ ) {
 	    const uint32_t v = v0 + i * BLOCK + threadIdx.x;
-	    buf[i] = v < nvec ? load4_guarded(x, org4 + ( v << 2 ), N)
-			      : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	    buf[i] = load4_raw(x, org4 + ( v << 2 ), N);
 	}
 #pragma unroll
 	for ( int i = 0; i < STAGE_VEC; i++ ) {
 	    const uint32_t v = v0 + i * BLOCK + threadIdx.x;
 	    if ( v < nvec )
-		store4_skewed(cfg, lds->slab, slab_cap, v << 2, head, buf[i]);
+		store4_skewed(cfg, lds->slab, slab_cap, v << 2, head, buf[i], org4 + ( v << 2 ), N);
 	}
     }
 }
 
 // SCAN: correlate every bit window of candidates c_pos[0..nq) into mags[0]
 template <bool USE_SLAB>
-__device__ void par_correlate( const DevCfg &cfg, const double *__restrict__ tw, StreamLds *lds,
+__device__ __forceinline__ void par_correlate( const DevCfg &cfg, const double *__restrict__ tw, StreamLds *lds,
 	const float *__restrict__ x, uint32_t N, uint32_t row_org, uint32_t nq )
 {
     const uint32_t n_bits = cfg.n_bits;
@@ -514,13 +606,17 @@ __device__ __forceinline__ void scan_part( const DevCfg &cfg, const double *__re
     __syncthreads();
 }
 
-// LDS accesses of one wave are executed in program order; this only stops the
-// compiler from moving them across the point
+// Make this wave's LDS writes visible to its other lanes.  LDS operations of one
+// wave execute in order, so no hardware wait is needed; wavefront-scope fences
+// only stop the compiler from reordering across the point.  (An inline-asm
+// wait with a "memory" clobber, or a workgroup-scope fence, makes hipcc drain
+// vmcnt as well -- which would stall on the global loads prefetched for the
+// next batch.)
 __device__ __forceinline__ void wave_lds_sync()
 {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 __device__ __forceinline__ uint32_t wave_min_u32( uint32_t v )
@@ -546,53 +642,135 @@ __device__ __forceinline__ uint32_t wave_max_u32( uint32_t v )
 // LATTICE: one worker wave's share of a batch -- windows [64 wkr, 64 wkr + 64)
 // of frames anchor + f * lock_advance, f < frames.  The wave stages exactly the
 // samples its own windows cover into its private LDS region and correlates
-// them; there is no dependency on the other waves.
-__device__ void worker_lattice( const DevCfg &cfg, const double *__restrict__ tw, StreamLds *lds,
+// them; there is no dependency on the other waves.  Window starts are
+// non-decreasing in window order (checked on the host), so the span is
+// [start of lane 0, start of lane 63 + B).  While it correlates, the loads for
+// the same share of the NEXT batch (the lattice continued) are already in
+// flight into `pbuf`, so HBM latency is off the critical path.
+__device__ __forceinline__ void worker_lattice( const DevCfg &cfg, const double *__restrict__ tw, StreamLds *lds,
 	const StreamLds::Cmd *cmd, const float *__restrict__ x, uint32_t N,
-	uint32_t region_floats, uint32_t region_cap, uint32_t wkr )
+	uint32_t region_floats, uint32_t region_cap, uint32_t lat_frames, uint32_t wkr,
+	float4 (&pbuf)[STAGE_VEC], uint32_t &pref_org4, uint64_t (&wcyc)[3] )
 {
+    const uint64_t t_in = MIFSK_CLOCK();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_bits = cfg.n_bits, B = cfg.bit_nsamples;
     const uint32_t anchor = cmd->anchor;
-    const uint32_t nwin = cmd->frames * n_bits;
+    const uint32_t frames = cmd->frames;
+    const uint32_t nwin = frames * n_bits;
     const uint32_t buf = cmd->buf;
     const uint32_t w = wkr * 64u + lane;
-    if ( wkr * 64u >= nwin )
+    if ( wkr * 64u >= nwin ) {
+	pref_org4 = 0xFFFFFFFFu;
 	return;					// nothing for this wave (uniform)
+    }
     const bool active = w < nwin;
     const uint32_t wc = active ? w : nwin - 1u;	// idle lanes shadow the last window
     const uint32_t f = udiv_magic(wc, n_bits, cfg.nbits_magic);
     const uint32_t k = wc - f * n_bits;
     const uint32_t a = anchor + f * cfg.lock_advance + cfg.bit_offset[k];
-    const uint32_t lo = wave_min_u32(a);
-    const uint32_t hi = wave_max_u32(a) + B;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)a, 63) + B;
     float *region = lds->slab + (size_t)wkr * region_floats;
 
     const uint32_t org4 = lo & ~3u;
     const uint32_t head = lo - org4;
     const uint32_t nvec = ( hi - org4 + 3 ) >> 2;
-    for ( uint32_t v0 = 0; v0 < nvec; v0 += 64 * STAGE_VEC ) {
-	float4 sbuf[STAGE_VEC];
+    if ( pref_org4 != org4 ) {
+	// nothing usable in flight: fetch this batch now
 #pragma unroll
 	for ( int i = 0; i < STAGE_VEC; i++ ) {
-	    const uint32_t v = v0 + i * 64 + lane;
-	    sbuf[i] = v < nvec ? load4_guarded(x, org4 + ( v << 2 ), N)
-			       : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-	}
-#pragma unroll
-	for ( int i = 0; i < STAGE_VEC; i++ ) {
-	    const uint32_t v = v0 + i * 64 + lane;
-	    if ( v < nvec )
-		store4_skewed(cfg, region, region_cap, v << 2, head, sbuf[i]);
+	    const uint32_t v = i * 64 + lane;
+	    pbuf[i] = load4_raw(x, org4 + ( v << 2 ), N);
 	}
     }
+    {
+	// Registers -> skewed LDS rows.  (q, r) = (row, column) of this lane's
+	// first sample; one round later the lane is 256 samples further on, so
+	// both advance by constants.  A round whose 64 float4s all lie inside
+	// [row 0, cap) x [0, N) needs no per-sample guards (uniform test).
+	const uint32_t skew = cfg.skew;
+	const uint32_t dq = udiv_magic(256u, B, cfg.div_magic), dr = 256u - dq * B;
+	const uint32_t first0 = lane << 2;
+	uint32_t q, r;
+	divmod_bit(cfg, first0 >= head ? first0 - head : 0u, q, r);
+#pragma unroll
+	for ( int i = 0; i < STAGE_VEC; i++ ) {
+	    const uint32_t v = i * 64 + lane;
+	    const uint32_t first = v << 2;
+	    const uint32_t vlast = i * 64 + 63u;		// last lane of the round
+	    const bool interior = ( i > 0 || head == 0 ) && B >= 4
+		&& vlast < nvec && ( vlast << 2 ) + 3 - head < region_cap
+		&& org4 + ( vlast << 2 ) + 3 < N;
+	    if ( interior ) {
+		float *d = region + ( first - head ) + q * skew;
+		const float4 sv = pbuf[i];
+		d[0] = sv.x;
+		d[1 + ( r + 1 >= B ? skew : 0u )] = sv.y;
+		d[2 + ( r + 2 >= B ? skew : 0u )] = sv.z;
+		d[3 + ( r + 3 >= B ? skew : 0u )] = sv.w;
+#if MIFSK_ABL == 3
+		{   // additive ablation: the same address arithmetic and stores once more
+		    uint32_t r2 = r, q2 = q;
+		    asm volatile("" : "+v"(r2), "+v"(q2));
+		    float *d2 = region + ( first - head ) + q2 * skew;
+		    d2[0] = sv.x;
+		    d2[1 + ( r2 + 1 >= B ? skew : 0u )] = sv.y;
+		    d2[2 + ( r2 + 2 >= B ? skew : 0u )] = sv.z;
+		    d2[3 + ( r2 + 3 >= B ? skew : 0u )] = sv.w;
+		}
+#endif
+	    } else if ( v < nvec ) {
+		store4_skewed(cfg, region, region_cap, first, head, pbuf[i], org4 + first, N);
+	    }
+	    if ( i > 0 || first0 >= head ) {		// (q, r) tracks first - head once that is >= 0
+		q += dq;
+		r += dr;
+		if ( r >= B ) {
+		    r -= B;
+		    q++;
+		}
+	    } else {
+		divmod_bit(cfg, first0 + 256u - head, q, r);
+	    }
+	}
+    }
+    // The same share of the next batch, assuming the lattice goes on (if it does
+    // not, the data is simply never used).  Issued unconditionally and with no
+    // control flow around it: any join point after the loads makes hipcc drain
+    // vmcnt, which would expose the HBM latency the prefetch is there to hide.
+    // (The host guarantees nvec <= 64 * STAGE_VEC, so there is no tail loop.)
+    {
+	const uint32_t nlo = lo + lat_frames * cfg.lock_advance;
+	const uint32_t norg4 = nlo & ~3u;
+#pragma unroll
+	for ( int i = 0; i < STAGE_VEC; i++ ) {
+	    const uint32_t v = i * 64 + lane;
+	    pbuf[i] = load4_raw(x, norg4 + ( v << 2 ), N);
+#if MIFSK_ABL == 6
+	    {
+		float4 extra = load4_raw(x, norg4 + ( v << 2 ) + 8192u, N);
+		asm volatile("" :: "v"(extra.x), "v"(extra.y), "v"(extra.z), "v"(extra.w));
+	    }
+#endif
+	}
+	pref_org4 = norg4;
+    }
     wave_lds_sync();
+    const uint64_t t_mid = MIFSK_CLOCK();
 
     double acc[4];
+#if MIFSK_ABL == 4
+    correlate_window(cfg, tw, region, a - lo, active, acc);
+    asm volatile("" :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));
+#endif
     correlate_window(cfg, tw, region, a - lo, active, acc);
     if ( active )
 	lds->mags[buf][w] = make_float2(band_mag(acc[0], acc[1], cfg.magscalar),
 					band_mag(acc[2], acc[3], cfg.magscalar));
+    const uint64_t t_out = MIFSK_CLOCK();
+    wcyc[0] += t_mid - t_in;
+    wcyc[1] += t_out - t_mid;
 }
 
 template <bool USE_SLAB>
@@ -650,7 +828,7 @@ struct Master {
     }
 
     // Start the pipeline at `anchor` (nothing is in flight).
-    __device__ void lattice_start( uint32_t anchor )
+    __device__ __forceinline__ void lattice_start( uint32_t anchor )
     {
 	const uint32_t frames = lattice_frames_at(anchor);
 	if ( !frames )
@@ -662,20 +840,31 @@ struct Master {
 
     // The batch in flight is the one the cursor has reached: start the workers
     // on the batch after it (speculatively) and score this one.
-    __device__ void lattice_advance()
+    __device__ __forceinline__ void lattice_advance()
     {
 	const uint32_t anchor = inflight_anchor, frames = inflight_frames, buf = inflight_buf;
 	const uint32_t next = anchor + frames * cfg.lock_advance;
 	publish_lattice(next, lattice_frames_at(next), buf ^ 1u);
-	const uint64_t t_w = clock64();
+	const uint64_t t_w = MIFSK_CLOCK();
 	__syncthreads();			// batch `anchor` is complete in mags[buf]
 	seq++;
-	const uint64_t t_c = clock64();
+	const uint64_t t_c = MIFSK_CLOCK();
 	cyc_wait += t_c - t_w;
 	n_lattice++;
 	if ( lane < frames ) {
+#if MIFSK_ABL == 2
+	    {
+		const FrameOut f2 = frame_confidence(&lds->mags[buf][lane * cfg.n_bits],
+						     cfg.req_mask[0] ^ 1u, cfg.req_val[0], cfg.n_bits);
+		asm volatile("" :: "v"(f2.conf), "v"(f2.ampl));
+	    }
+#endif
+#if MIFSK_ABL == 7 || MIFSK_ABL == 8
+	    FrameOut fo; fo.conf = 5.0f + lds->mags[buf][lane * cfg.n_bits].x * 1e-30f; fo.ampl = 1.0f; fo.bits = 0x2AB;
+#else
 	    const FrameOut fo = frame_confidence(&lds->mags[buf][lane * cfg.n_bits],
-						 cfg.expect[0], cfg.n_bits);
+						 cfg.req_mask[0], cfg.req_val[0], cfg.n_bits);
+#endif
 	    lds->c_conf[lane] = fo.conf;
 	    lds->c_ampl[lane] = fo.ampl;
 	    lds->c_bits[lane] = fo.bits;
@@ -687,11 +876,11 @@ struct Master {
 	    lds->c_kind = 0;
 	}
 	wave_lds_sync();
-	cyc_conf += clock64() - t_c;
+	cyc_conf += MIFSK_CLOCK() - t_c;
     }
 
     // SCAN: evaluate candidates c_pos[0..nq) (already in LDS) spanning [lo, hi)
-    __device__ void evaluate( uint32_t nq, uint32_t kind, uint32_t lo, uint32_t hi )
+    __device__ __forceinline__ void evaluate( uint32_t nq, uint32_t kind, uint32_t lo, uint32_t hi )
     {
 	bool restage = false;
 	if ( USE_SLAB && ( lo < slab_lo || hi > slab_hi ) ) {
@@ -710,25 +899,25 @@ struct Master {
 	inflight = false;		// the barrier below also retires any batch in flight
 	n_batches++;
 	n_positions += nq;
-	const uint64_t t_par = clock64();
+	const uint64_t t_par = MIFSK_CLOCK();
 	__syncthreads();			// command (and c_pos[]) published
 	seq++;
 	scan_part<USE_SLAB>(cfg, tw, lds, c, x, N, slab_cap);
-	const uint64_t t_conf = clock64();
+	const uint64_t t_conf = MIFSK_CLOCK();
 	cyc_par += t_conf - t_par;
 	if ( lane < nq ) {
 	    const FrameOut f = frame_confidence(&lds->mags[0][lane * cfg.n_bits],
-						cfg.expect[kind], cfg.n_bits);
+						cfg.req_mask[kind], cfg.req_val[kind], cfg.n_bits);
 	    lds->c_conf[lane] = f.conf;
 	    lds->c_ampl[lane] = f.ampl;
 	    lds->c_bits[lane] = f.bits;
 	}
 	wave_lds_sync();
-	cyc_conf += clock64() - t_conf;
+	cyc_conf += MIFSK_CLOCK() - t_conf;
     }
 
     // fsk_find_frame at cursor `base` (absolute)
-    __device__ ScanResult scan( uint32_t base, const ZigZag &zz, uint32_t first,
+    __device__ __forceinline__ ScanResult scan( uint32_t base, const ZigZag &zz, uint32_t first,
 	    float limit, uint32_t kind )
     {
 	ScanResult r;
@@ -839,7 +1028,7 @@ __device__ __forceinline__ float lane_bcast( float v, uint32_t src )
 
 // The reference's receive loop (minimodem.c:1137-1463); executed by wave 0 only.
 template <bool USE_SLAB>
-__device__ void master_loop( const DevCfg &cfg, const double *__restrict__ tw,
+__device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__restrict__ tw,
 	const mifsk_demod_io &io, uint32_t slab_cap, uint32_t lat_frames, StreamLds *lds )
 {
     const uint32_t s = blockIdx.x;
@@ -871,7 +1060,7 @@ __device__ void master_loop( const DevCfg &cfg, const double *__restrict__ tw,
     uint32_t status = 0;
     uint32_t n_iter = 0, n_bulk = 0, n_refine = 0;
     uint64_t cyc_bulk = 0;
-    const uint64_t t_start = clock64();
+    const uint64_t t_start = MIFSK_CLOCK();
 
     const ZigZag zc0(cfg.try_first[0], cfg.try_max[0], cfg.try_step[0]);
     const ZigZag zc1(cfg.try_first[1], cfg.try_max[1], cfg.try_step[1]);
@@ -889,7 +1078,7 @@ __device__ void master_loop( const DevCfg &cfg, const double *__restrict__ tw,
 	// that fails any of them falls through to the general path below.
 	// ------------------------------------------------------------------
 	if ( carrier && advance && advance <= N - base ) {
-	    const uint64_t t_bulk = clock64();
+	    const uint64_t t_bulk = MIFSK_CLOCK();
 	    const uint32_t first = cfg.try_first[1];
 	    const uint32_t nb = base + advance;		// cursor of the next iteration
 	    const uint32_t p = nb + first;
@@ -917,7 +1106,27 @@ __device__ void master_loop( const DevCfg &cfg, const double *__restrict__ tw,
 		float t = track_amplitude, pk = peak_confidence;
 		float sc = confidence_total, sa = amplitude_total;
 		float my_t = t, my_pk = pk, my_sc = sc, my_sa = sa;
+#if MIFSK_ABL == 5
+#if MIFSK_ABL == 8
+		for ( uint32_t k = 0; k < 1; k++ ) {
+#else
 		for ( uint32_t k = 0; k < K; k++ ) {
+#endif
+		    const float c = lane_bcast(cv, k);
+		    const float a = lane_bcast(av, k);
+		    const bool me = lane == k;
+		    my_t = me ? t : my_t; my_pk = me ? pk : my_pk; my_sc = me ? sc : my_sc; my_sa = me ? sa : my_sa;
+		    t = ( t + a ) / 2.0f; pk = pk < c ? c : pk; sc += c; sa += a;
+		}
+		asm volatile("" :: "v"(my_t), "v"(my_pk), "v"(my_sc), "v"(my_sa));
+		t = track_amplitude; pk = peak_confidence; sc = confidence_total; sa = amplitude_total;
+		my_t = t; my_pk = pk; my_sc = sc; my_sa = sa;
+#endif
+#if MIFSK_ABL == 8
+		for ( uint32_t k = 0; k < 1; k++ ) {
+#else
+		for ( uint32_t k = 0; k < K; k++ ) {
+#endif
 		    const float c = lane_bcast(cv, k);
 		    const float a = lane_bcast(av, k);
 		    const bool me = lane == k;
@@ -1001,7 +1210,7 @@ __device__ void master_loop( const DevCfg &cfg, const double *__restrict__ tw,
 		ctx.lattice_advance();
 		progressed = true;
 	    }
-	    cyc_bulk += clock64() - t_bulk;
+	    cyc_bulk += MIFSK_CLOCK() - t_bulk;
 	    if ( progressed )
 		continue;
 	}
@@ -1176,7 +1385,7 @@ __device__ void master_loop( const DevCfg &cfg, const double *__restrict__ tw,
 	    c[MIFSK_CNT_CACHE_HITS] = ctx.n_hits;
 	    c[MIFSK_CNT_POSITIONS] = ctx.n_positions;
 	    c[MIFSK_CNT_LATTICE_BATCHES] = ctx.n_lattice;
-	    c[MIFSK_CNT_CYC_TOTAL] = clock64() - t_start;
+	    c[MIFSK_CNT_CYC_TOTAL] = MIFSK_CLOCK() - t_start;
 	    c[MIFSK_CNT_CYC_PARALLEL] = ctx.cyc_par;
 	    c[MIFSK_CNT_CYC_WAIT] = ctx.cyc_wait;
 	    c[MIFSK_CNT_CYC_CONFIDENCE] = ctx.cyc_conf;
@@ -1187,13 +1396,162 @@ __device__ void master_loop( const DevCfg &cfg, const double *__restrict__ tw,
     __syncthreads();				// releases the workers with "exit"
 }
 
-template <bool USE_SLAB>
-__global__ __launch_bounds__(BLOCK)
-void demod_kernel( DevCfg cfg, const double *__restrict__ tw, mifsk_demod_io io,
-	uint32_t slab_cap, uint32_t lat_frames, uint32_t region_floats, uint32_t region_cap )
+// LATTICE, linear variant (cfg.lat_linear): the bit length, every bit offset and
+// the frame step are multiples of 4 samples, so every window of the wave starts
+// a multiple of 16 bytes after the first one.  The region then holds the span
+// [lo, hi) unskewed with sample lo at its (16-byte aligned) base:
+//   stage     one (possibly unaligned) 16-byte global load and ONE ds_write_b128
+//             per lane per KiB -- no per-sample address arithmetic at all;
+//   correlate two ds_read_b128 per 8 samples (lanes one bit length apart are
+//             2-way bank conflicted on b128, the same LDS time as the
+//             conflict-free b32 reads of the skewed layout, a quarter of the
+//             instructions).
+// Same arithmetic, same order: results are identical to the skewed variant.
+typedef float float4_u __attribute__((ext_vector_type(4), aligned(4)));
+
+__device__ __forceinline__ float4 load4_unaligned( const float *__restrict__ x, uint32_t a, uint32_t N )
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    StreamLds *lds = reinterpret_cast<StreamLds *>(smem);
+    const uint32_t aa = ( a + 3 < N && a + 3 >= a ) ? a : 0u;	// tail vectors are re-read by element
+    const float4_u s = *reinterpret_cast<const float4_u *>(x + aa);
+    return make_float4(s.x, s.y, s.z, s.w);
+}
+
+__device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const double *__restrict__ tw,
+	StreamLds *lds, const StreamLds::Cmd *cmd, const float *__restrict__ x, uint32_t N,
+	uint32_t region_floats, uint32_t lat_frames, uint32_t wkr,
+	float4 (&pbuf)[STAGE_VEC], uint32_t &pref_org4 )
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_bits = cfg.n_bits, B = cfg.bit_nsamples;
+    const uint32_t anchor = cmd->anchor;
+    const uint32_t nwin = cmd->frames * n_bits;
+    const uint32_t buf = cmd->buf;
+    const uint32_t w = wkr * 64u + lane;
+    if ( wkr * 64u >= nwin ) {
+	pref_org4 = 0xFFFFFFFFu;
+	return;					// nothing for this wave (uniform)
+    }
+    const bool active = w < nwin;
+    const uint32_t wc = active ? w : nwin - 1u;	// idle lanes shadow the last window
+    const uint32_t f = udiv_magic(wc, n_bits, cfg.nbits_magic);
+    const uint32_t k = wc - f * n_bits;
+    const uint32_t a = anchor + f * cfg.lock_advance + cfg.bit_offset[k];
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)a, 63) + B;
+    float *region = lds->slab + (size_t)wkr * region_floats;
+    // + XCH: the last chunk of the last window may run past it (zero twiddles)
+    const uint32_t nvec = ( hi - lo + XCH + 3 ) >> 2;
+
+    if ( pref_org4 != lo ) {
+	// nothing usable in flight: fetch this batch now
+#pragma unroll
+	for ( int i = 0; i < STAGE_VEC; i++ )
+	    pbuf[i] = load4_unaligned(x, lo + ( ( i * 64 + lane ) << 2 ), N);
+    }
+#pragma unroll
+    for ( int i = 0; i < STAGE_VEC; i++ ) {
+	const uint32_t v = i * 64 + lane;
+	const uint32_t vlast = i * 64 + 63u;
+	float4 sv = pbuf[i];
+	const bool interior = vlast < nvec && lo + ( vlast << 2 ) + 3 < N;	// uniform
+	if ( !interior ) {
+	    const uint32_t e = lo + ( v << 2 );
+	    sv.x = ( e < N ) ? x[e] : 0.0f;
+	    sv.y = ( e + 1 < N && e + 1 > e ) ? x[e + 1] : 0.0f;
+	    sv.z = ( e + 2 < N && e + 2 > e ) ? x[e + 2] : 0.0f;
+	    sv.w = ( e + 3 < N && e + 3 > e ) ? x[e + 3] : 0.0f;
+	}
+	if ( v < nvec )
+	    *reinterpret_cast<float4 *>(region + ( v << 2 )) = sv;
+    }
+    // the same share of the next batch, assuming the lattice goes on; issued
+    // unconditionally and with no control flow after it (see worker_lattice)
+    {
+	const uint32_t nlo = lo + lat_frames * cfg.lock_advance;
+#pragma unroll
+	for ( int i = 0; i < STAGE_VEC; i++ )
+	    pbuf[i] = load4_unaligned(x, nlo + ( ( i * 64 + lane ) << 2 ), N);
+	pref_org4 = nlo;
+    }
+    wave_lds_sync();
+
+    const float *p = region + ( a - lo );
+    double mr = 0.0, mi = 0.0, sr = 0.0, si = 0.0;
+    for ( uint32_t n0 = 0; n0 < B; n0 += XCH ) {
+	tw8 ta, tb, tc, td;
+	twiddle_fetch(tw + 4 * (size_t)n0, ta, tb, tc, td);
+	const float4 x0 = *reinterpret_cast<const float4 *>(p + n0);
+	const float4 x1 = *reinterpret_cast<const float4 *>(p + n0 + 4);
+	twiddle_wait();
+	MIFSK_FMA4(x0.x, ta, 0);  MIFSK_FMA4(x0.y, ta, 1);
+	MIFSK_FMA4(x0.z, tb, 0);  MIFSK_FMA4(x0.w, tb, 1);
+	MIFSK_FMA4(x1.x, tc, 0);  MIFSK_FMA4(x1.y, tc, 1);
+	MIFSK_FMA4(x1.z, td, 0);  MIFSK_FMA4(x1.w, td, 1);
+    }
+    if ( active )
+	lds->mags[buf][w] = make_float2(band_mag(mr, mi, cfg.magscalar),
+					band_mag(sr, si, cfg.magscalar));
+}
+
+// The worker waves' whole life.  A real (non-inlined) function on purpose: it
+// gets its own register allocation, so the 64 SGPRs of twiddles that the
+// correlator wants in flight do not compete with the master's scalar state.
+template <bool USE_SLAB>
+__device__ __forceinline__ void worker_main( const DevCfg *__restrict__ cfgp,
+	const double *__restrict__ tw, StreamLds *lds, const float *__restrict__ x, uint32_t N,
+	uint32_t slab_cap, uint32_t lat_frames, uint32_t region_floats, uint32_t region_cap,
+	uint64_t *counters )
+{
+    const DevCfg &cfg = *cfgp;
+    const uint32_t wkr = ( threadIdx.x >> 6 ) - 1u;
+    float4 pbuf[STAGE_VEC];
+#pragma unroll
+    for ( int i = 0; i < STAGE_VEC; i++ )
+	pbuf[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    uint32_t pref_org4 = 0xFFFFFFFFu;
+    uint64_t wcyc[3] = { 0, 0, 0 };
+    for ( uint32_t seq = 0; ; seq++ ) {
+	const uint64_t t_b = MIFSK_CLOCK();
+	__syncthreads();			// command number `seq` has been published
+	wcyc[2] += MIFSK_CLOCK() - t_b;
+	const StreamLds::Cmd *cmd = &lds->cmd[seq & 1u];
+	const uint32_t op = cmd->op;
+	if ( op == CMD_EXIT )
+	    break;
+	if ( op == CMD_SCAN ) {
+	    scan_part<USE_SLAB>(cfg, tw, lds, cmd, x, N, slab_cap);
+	    pref_org4 = 0xFFFFFFFFu;
+	} else if ( USE_SLAB && op == CMD_LATTICE ) {
+	    if ( cfg.lat_linear )
+		worker_lattice_linear(cfg, tw, lds, cmd, x, N, region_floats, lat_frames,
+				      wkr, pbuf, pref_org4);
+	    else
+		worker_lattice(cfg, tw, lds, cmd, x, N, region_floats, region_cap, lat_frames,
+			       wkr, pbuf, pref_org4, wcyc);
+	}
+    }
+#ifdef MIFSK_PROFILE
+    if ( threadIdx.x == 64 && counters ) {
+	counters[13] = wcyc[0];
+	counters[14] = wcyc[1];
+	counters[15] = wcyc[2];
+    }
+#else
+    (void)counters;
+#endif
+}
+
+template <bool USE_SLAB>
+__global__ __launch_bounds__(BLOCK, 4)
+void demod_kernel( const DevCfg *__restrict__ cfgp, const double *__restrict__ tw,
+	mifsk_demod_io io, uint32_t slab_cap, uint32_t lat_frames, uint32_t region_floats,
+	uint32_t region_cap )
+{
+    StreamLds *lds = reinterpret_cast<StreamLds *>(mifsk_smem);
+    // the configuration lives in device memory (uniform -> scalar loads); it is
+    // NOT a by-value kernel argument so that the worker body below can be a real
+    // function with its own register allocation
+    const DevCfg &cfg = *cfgp;
 
     if ( threadIdx.x == 0 ) {
 	lds->c_n = 0;
@@ -1208,21 +1566,10 @@ void demod_kernel( DevCfg cfg, const double *__restrict__ tw, mifsk_demod_io io,
 	__builtin_amdgcn_s_setprio(3);
 	master_loop<USE_SLAB>(cfg, tw, io, slab_cap, lat_frames, lds);
     } else {
-	const uint32_t s = blockIdx.x;
-	const float *x = io.d_samples + (size_t)s * io.stream_stride;
-	const uint32_t N = io.d_nsamples ? io.d_nsamples[s] : io.nsamples;
-	const uint32_t wkr = ( threadIdx.x >> 6 ) - 1u;
-	for ( uint32_t seq = 0; ; seq++ ) {
-	    __syncthreads();			// command number `seq` has been published
-	    const StreamLds::Cmd *cmd = &lds->cmd[seq & 1u];
-	    const uint32_t op = cmd->op;
-	    if ( op == CMD_EXIT )
-		break;
-	    if ( op == CMD_SCAN )
-		scan_part<USE_SLAB>(cfg, tw, lds, cmd, x, N, slab_cap);
-	    else if ( USE_SLAB && op == CMD_LATTICE )
-		worker_lattice(cfg, tw, lds, cmd, x, N, region_floats, region_cap, wkr);
-	}
+	worker_main<USE_SLAB>(cfgp, tw, lds, io.d_samples + (size_t)blockIdx.x * io.stream_stride,
+			      io.d_nsamples ? io.d_nsamples[blockIdx.x] : io.nsamples,
+			      slab_cap, lat_frames, region_floats, region_cap,
+			      io.d_counters ? io.d_counters + (size_t)blockIdx.x * MIFSK_NCOUNTERS : nullptr);
     }
 }
 
@@ -1262,21 +1609,21 @@ static inline int hip_rc( hipError_t e )
     return e == hipSuccess ? 0 : -5 /* -EIO */;
 }
 
-int launch_find_frame_batch( const DevCfg &cfg, const double *d_tw,
+int launch_find_frame_batch( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_tw,
 	const float *d_samples, const mifsk_search *d_problems,
 	mifsk_search_result *d_results, int nproblems, void *stream )
 {
     if ( nproblems <= 0 )
 	return 0;
     hipLaunchKernelGGL(find_frame_kernel, dim3((unsigned)nproblems), dim3(64), 0,
-		       (hipStream_t)stream, cfg, d_tw, d_samples, d_problems, d_results);
+		       (hipStream_t)stream, d_cfg, d_tw, d_samples, d_problems, d_results);
     return hip_rc(hipGetLastError());
 }
 
 static constexpr size_t kLdsHeader = offsetof(StreamLds, slab);
 static constexpr size_t kLdsPerCu = 160 * 1024;
 
-int launch_demod_batch( const DevCfg &cfg, const double *d_tw,
+int launch_demod_batch( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_tw,
 	const mifsk_demod_io &io, void *stream )
 {
     if ( io.nstreams <= 0 )
@@ -1295,7 +1642,13 @@ int launch_demod_batch( const DevCfg &cfg, const double *d_tw,
     // lanes; each worker wave's region must hold the samples its 64 windows span
     auto region_samples = [&]( uint32_t frames ) -> uint32_t {
 	const uint32_t nwin = frames * cfg.n_bits;
-	uint32_t worst = 0;
+	uint32_t worst = 0, prev = 0;
+	for ( uint32_t w = 0; w < nwin; w++ ) {		// the kernel relies on ordered starts
+	    const uint32_t a = ( w / cfg.n_bits ) * cfg.lock_advance + cfg.bit_offset[w % cfg.n_bits];
+	    if ( a < prev )
+		return 0xFFFFFFF0u;
+	    prev = a;
+	}
 	for ( uint32_t w0 = 0; w0 < nwin; w0 += 64 ) {
 	    uint32_t lo = 0xFFFFFFFFu, hi = 0;
 	    for ( uint32_t w = w0; w < w0 + 64 && w < nwin; w++ ) {
@@ -1305,7 +1658,7 @@ int launch_demod_batch( const DevCfg &cfg, const double *d_tw,
 	    }
 	    worst = hi - lo > worst ? hi - lo : worst;
 	}
-	return ( worst + 4 + 3 ) & ~3u;		// + up to 3 samples of alignment head
+	return ( worst + 4 + XCH + 3 ) & ~3u;	// + alignment head + one chunk of overrun
     };
     uint32_t lat_frames = LAT_LANES / cfg.n_bits;
     if ( lat_frames > P_CAP ) lat_frames = P_CAP;
@@ -1314,7 +1667,7 @@ int launch_demod_batch( const DevCfg &cfg, const double *d_tw,
     while ( lat_frames ) {
 	region_cap = region_samples(lat_frames);
 	region_floats = floats_for(region_cap);
-	if ( kLdsHeader + NWORKERS * region_floats * 4 <= budget_small
+	if ( region_cap <= 64u * STAGE_VEC * 4u - 4u && kLdsHeader + NWORKERS * region_floats * 4 <= budget_small
 		&& NWORKERS * region_floats >= floats_for(reach + 4) )
 	    break;
 	lat_frames--;
@@ -1351,11 +1704,11 @@ int launch_demod_batch( const DevCfg &cfg, const double *d_tw,
 	if ( e != hipSuccess )
 	    return hip_rc(e);
 	hipLaunchKernelGGL(demod_kernel<true>, dim3((unsigned)io.nstreams), dim3(BLOCK),
-			   lds_bytes, st, cfg, d_tw, io, slab_cap, lat_frames,
+			   lds_bytes, st, d_cfg, d_tw, io, slab_cap, lat_frames,
 			   (uint32_t)region_floats, region_cap);
     } else {
 	hipLaunchKernelGGL(demod_kernel<false>, dim3((unsigned)io.nstreams), dim3(BLOCK),
-			   kLdsHeader + 16, st, cfg, d_tw, io, 0u, 0u, 0u, 0u);
+			   kLdsHeader + 16, st, d_cfg, d_tw, io, 0u, 0u, 0u, 0u);
     }
     return hip_rc(hipGetLastError());
 }
