@@ -37,7 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 NSTREAMS_PER_GPU = 1024
-NSAMPLES = 480000		# 10 s at 48 kHz
+NSAMPLES = int(os.environ.get("MIFSK_BENCH_NSAMPLES", "480000"))	# 10 s at 48 kHz (override: experiments only)
 HBM_PEAK = 8.0e12		# B/s, MI355X spec (MI355X_MICROARCH.md)
 
 

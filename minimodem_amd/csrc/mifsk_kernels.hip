@@ -1419,8 +1419,9 @@ __device__ __forceinline__ float4 load4_unaligned( const float *__restrict__ x, 
 __device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const double *__restrict__ tw,
 	StreamLds *lds, const StreamLds::Cmd *cmd, const float *__restrict__ x, uint32_t N,
 	uint32_t region_floats, uint32_t lat_frames, uint32_t wkr,
-	float4 (&pbuf)[STAGE_VEC], uint32_t &pref_org4 )
+	float4 (&pbuf)[STAGE_VEC], uint32_t &pref_org4, uint64_t (&wcyc)[3] )
 {
+    const uint64_t t_in = MIFSK_CLOCK();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_bits = cfg.n_bits, B = cfg.bit_nsamples;
     const uint32_t anchor = cmd->anchor;
@@ -1474,6 +1475,7 @@ __device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const 
 	pref_org4 = nlo;
     }
     wave_lds_sync();
+    const uint64_t t_mid = MIFSK_CLOCK();
 
     const float *p = region + ( a - lo );
     double mr = 0.0, mi = 0.0, sr = 0.0, si = 0.0;
@@ -1491,6 +1493,9 @@ __device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const 
     if ( active )
 	lds->mags[buf][w] = make_float2(band_mag(mr, mi, cfg.magscalar),
 					band_mag(sr, si, cfg.magscalar));
+    const uint64_t t_out = MIFSK_CLOCK();
+    wcyc[0] += t_mid - t_in;
+    wcyc[1] += t_out - t_mid;
 }
 
 // The worker waves' whole life.  A real (non-inlined) function on purpose: it
@@ -1524,7 +1529,7 @@ __device__ __forceinline__ void worker_main( const DevCfg *__restrict__ cfgp,
 	} else if ( USE_SLAB && op == CMD_LATTICE ) {
 	    if ( cfg.lat_linear )
 		worker_lattice_linear(cfg, tw, lds, cmd, x, N, region_floats, lat_frames,
-				      wkr, pbuf, pref_org4);
+				      wkr, pbuf, pref_org4, wcyc);
 	    else
 		worker_lattice(cfg, tw, lds, cmd, x, N, region_floats, region_cap, lat_frames,
 			       wkr, pbuf, pref_org4, wcyc);
