@@ -48,7 +48,7 @@ namespace mifsk {
 
 constexpr int BLOCK = 256;	// threads per stream workgroup (4 waves)
 constexpr int P_CAP = 64;	// candidate positions per batch (= one wave of lanes)
-constexpr int W_CAP = 256;	// bit windows per batch (LDS scratch)
+constexpr int W_CAP = 448;	// bit windows per batch (LDS scratch)
 
 // ---------------------------------------------------------------------------
 // arithmetic shared by every kernel
@@ -782,7 +782,7 @@ struct Master {
     StreamLds		*lds;
     uint32_t		slab_cap;	// SCAN: samples the whole slab can hold
     uint32_t		slab_lo, slab_hi;	// SCAN: absolute range currently staged
-    uint32_t		lat_frames;	// LATTICE: frames per batch (0 = lattice off)
+    uint32_t		lat_batch;	// LATTICE: frames per batch = per round x rounds (0 = off)
     uint32_t		lane;
     // the lattice batch the workers are computing right now
     bool		inflight;
@@ -795,7 +795,7 @@ struct Master {
     __device__ __forceinline__ Master( const DevCfg &c, const double *t, const float *xs,
 	    uint32_t n, StreamLds *l, uint32_t cap, uint32_t lf )
 	: cfg(c), tw(t), x(xs), N(n), lds(l), slab_cap(cap), slab_lo(0), slab_hi(0),
-	  lat_frames(lf), lane(threadIdx.x), inflight(false), inflight_anchor(0),
+	  lat_batch(lf), lane(threadIdx.x), inflight(false), inflight_anchor(0),
 	  inflight_frames(0), inflight_buf(0), seq(0) {}
 
     // the slot for the command that the NEXT barrier publishes
@@ -807,7 +807,7 @@ struct Master {
 	if ( anchor >= N )
 	    return 0;
 	const uint32_t left = udiv_magic(N - anchor - 1u, cfg.lock_advance, cfg.la_magic) + 1u;
-	return left < lat_frames ? left : lat_frames;
+	return left < lat_batch ? left : lat_batch;
     }
 
     // publish a LATTICE (or IDLE) command; the caller then meets the barrier
@@ -1341,7 +1341,7 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 	// carrier is held: (re)start the lattice pipeline where the next
 	// iteration will search first, unless a matching batch is already in
 	// flight or already scored
-	if ( ctx.lat_frames && advance <= N - base ) {
+	if ( ctx.lat_batch && advance <= N - base ) {
 	    const uint32_t p = base + advance + cfg.try_first[1];
 	    const bool cached = __ballot(lane >= lds->c_q && lane < lds->c_n
 					 && lds->c_kind == 0u && lds->c_pos[lane] == p) != 0ULL;
@@ -1418,84 +1418,95 @@ __device__ __forceinline__ float4 load4_unaligned( const float *__restrict__ x, 
 
 __device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const double *__restrict__ tw,
 	StreamLds *lds, const StreamLds::Cmd *cmd, const float *__restrict__ x, uint32_t N,
-	uint32_t region_floats, uint32_t lat_frames, uint32_t wkr,
+	uint32_t region_floats, uint32_t lat_frames, uint32_t wkr, uint32_t done,
 	float4 (&pbuf)[STAGE_VEC], uint32_t &pref_org4, uint64_t (&wcyc)[3] )
 {
-    const uint64_t t_in = MIFSK_CLOCK();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_bits = cfg.n_bits, B = cfg.bit_nsamples;
-    const uint32_t anchor = cmd->anchor;
-    const uint32_t nwin = cmd->frames * n_bits;
     const uint32_t buf = cmd->buf;
-    const uint32_t w = wkr * 64u + lane;
-    if ( wkr * 64u >= nwin ) {
-	pref_org4 = 0xFFFFFFFFu;
-	return;					// nothing for this wave (uniform)
-    }
-    const bool active = w < nwin;
-    const uint32_t wc = active ? w : nwin - 1u;	// idle lanes shadow the last window
-    const uint32_t f = udiv_magic(wc, n_bits, cfg.nbits_magic);
-    const uint32_t k = wc - f * n_bits;
-    const uint32_t a = anchor + f * cfg.lock_advance + cfg.bit_offset[k];
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)a, 63) + B;
     float *region = lds->slab + (size_t)wkr * region_floats;
-    // + XCH: the last chunk of the last window may run past it (zero twiddles)
-    const uint32_t nvec = ( hi - lo + XCH + 3 ) >> 2;
-
-    if ( pref_org4 != lo ) {
-	// nothing usable in flight: fetch this batch now
-#pragma unroll
-	for ( int i = 0; i < STAGE_VEC; i++ )
-	    pbuf[i] = load4_unaligned(x, lo + ( ( i * 64 + lane ) << 2 ), N);
-    }
-#pragma unroll
-    for ( int i = 0; i < STAGE_VEC; i++ ) {
-	const uint32_t v = i * 64 + lane;
-	const uint32_t vlast = i * 64 + 63u;
-	float4 sv = pbuf[i];
-	const bool interior = vlast < nvec && lo + ( vlast << 2 ) + 3 < N;	// uniform
-	if ( !interior ) {
-	    const uint32_t e = lo + ( v << 2 );
-	    sv.x = ( e < N ) ? x[e] : 0.0f;
-	    sv.y = ( e + 1 < N && e + 1 > e ) ? x[e + 1] : 0.0f;
-	    sv.z = ( e + 2 < N && e + 2 > e ) ? x[e + 2] : 0.0f;
-	    sv.w = ( e + 3 < N && e + 3 > e ) ? x[e + 3] : 0.0f;
-	}
-	if ( v < nvec )
-	    *reinterpret_cast<float4 *>(region + ( v << 2 )) = sv;
-    }
-    // the same share of the next batch, assuming the lattice goes on; issued
-    // unconditionally and with no control flow after it (see worker_lattice)
+    // A batch is scored by the master in one go but correlated here in ROUNDS
+    // of lat_frames frames (what the regions hold); the lattice simply
+    // continues from one round into the next, and so does the prefetch.
+    const uint32_t total = cmd->frames;
     {
-	const uint32_t nlo = lo + lat_frames * cfg.lock_advance;
-#pragma unroll
-	for ( int i = 0; i < STAGE_VEC; i++ )
-	    pbuf[i] = load4_unaligned(x, nlo + ( ( i * 64 + lane ) << 2 ), N);
-	pref_org4 = nlo;
-    }
-    wave_lds_sync();
-    const uint64_t t_mid = MIFSK_CLOCK();
+	const uint64_t t_in = MIFSK_CLOCK();
+	const uint32_t frames = total - done < lat_frames ? total - done : lat_frames;
+	const uint32_t anchor = cmd->anchor + done * cfg.lock_advance;
+	const uint32_t nwin = frames * n_bits;
+	const uint32_t w = wkr * 64u + lane;
+	if ( wkr * 64u >= nwin ) {
+	    pref_org4 = 0xFFFFFFFFu;
+	    return;				// nothing for this wave this round (uniform)
+	}
+	const bool active = w < nwin;
+	const uint32_t wc = active ? w : nwin - 1u;	// idle lanes shadow the last window
+	const uint32_t f = udiv_magic(wc, n_bits, cfg.nbits_magic);
+	const uint32_t k = wc - f * n_bits;
+	const uint32_t a = anchor + f * cfg.lock_advance + cfg.bit_offset[k];
+	const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
+	const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)a, 63) + B;
+	// + XCH: the last chunk of the last window may run past it (zero twiddles)
+	const uint32_t nvec = ( hi - lo + XCH + 3 ) >> 2;
 
-    const float *p = region + ( a - lo );
-    double mr = 0.0, mi = 0.0, sr = 0.0, si = 0.0;
-    for ( uint32_t n0 = 0; n0 < B; n0 += XCH ) {
-	tw8 ta, tb, tc, td;
-	twiddle_fetch(tw + 4 * (size_t)n0, ta, tb, tc, td);
-	const float4 x0 = *reinterpret_cast<const float4 *>(p + n0);
-	const float4 x1 = *reinterpret_cast<const float4 *>(p + n0 + 4);
-	twiddle_wait();
-	MIFSK_FMA4(x0.x, ta, 0);  MIFSK_FMA4(x0.y, ta, 1);
-	MIFSK_FMA4(x0.z, tb, 0);  MIFSK_FMA4(x0.w, tb, 1);
-	MIFSK_FMA4(x1.x, tc, 0);  MIFSK_FMA4(x1.y, tc, 1);
-	MIFSK_FMA4(x1.z, td, 0);  MIFSK_FMA4(x1.w, td, 1);
+	if ( pref_org4 != lo ) {
+	    // nothing usable in flight: fetch this round now
+#pragma unroll
+	    for ( int i = 0; i < STAGE_VEC; i++ )
+		pbuf[i] = load4_unaligned(x, lo + ( ( i * 64 + lane ) << 2 ), N);
+	}
+#pragma unroll
+	for ( int i = 0; i < STAGE_VEC; i++ ) {
+	    const uint32_t v = i * 64 + lane;
+	    const uint32_t vlast = i * 64 + 63u;
+	    float4 sv = pbuf[i];
+	    const bool interior = vlast < nvec && lo + ( vlast << 2 ) + 3 < N;	// uniform
+	    if ( !interior ) {
+		const uint32_t e = lo + ( v << 2 );
+		sv.x = ( e < N ) ? x[e] : 0.0f;
+		sv.y = ( e + 1 < N && e + 1 > e ) ? x[e + 1] : 0.0f;
+		sv.z = ( e + 2 < N && e + 2 > e ) ? x[e + 2] : 0.0f;
+		sv.w = ( e + 3 < N && e + 3 > e ) ? x[e + 3] : 0.0f;
+	    }
+	    if ( v < nvec )
+		*reinterpret_cast<float4 *>(region + ( v << 2 )) = sv;
+	}
+	// The same share of the next round (of this batch or the next), assuming
+	// the lattice goes on; issued unconditionally and with no control flow
+	// after it (see worker_lattice).  (A second, alternating register buffer
+	// -- two rounds of look-ahead -- does not fit the 128-VGPR budget that
+	// four workgroups per CU impose: it spills into the hot loop.)
+	{
+	    const uint32_t nlo = lo + lat_frames * cfg.lock_advance;
+#pragma unroll
+	    for ( int i = 0; i < STAGE_VEC; i++ )
+		pbuf[i] = load4_unaligned(x, nlo + ( ( i * 64 + lane ) << 2 ), N);
+	    pref_org4 = nlo;
+	}
+	wave_lds_sync();
+	const uint64_t t_mid = MIFSK_CLOCK();
+
+	const float *p = region + ( a - lo );
+	double mr = 0.0, mi = 0.0, sr = 0.0, si = 0.0;
+	for ( uint32_t n0 = 0; n0 < B; n0 += XCH ) {
+	    tw8 ta, tb, tc, td;
+	    twiddle_fetch(tw + 4 * (size_t)n0, ta, tb, tc, td);
+	    const float4 x0 = *reinterpret_cast<const float4 *>(p + n0);
+	    const float4 x1 = *reinterpret_cast<const float4 *>(p + n0 + 4);
+	    twiddle_wait();
+	    MIFSK_FMA4(x0.x, ta, 0);  MIFSK_FMA4(x0.y, ta, 1);
+	    MIFSK_FMA4(x0.z, tb, 0);  MIFSK_FMA4(x0.w, tb, 1);
+	    MIFSK_FMA4(x1.x, tc, 0);  MIFSK_FMA4(x1.y, tc, 1);
+	    MIFSK_FMA4(x1.z, td, 0);  MIFSK_FMA4(x1.w, td, 1);
+	}
+	if ( active )
+	    lds->mags[buf][done * n_bits + w] = make_float2(band_mag(mr, mi, cfg.magscalar),
+							   band_mag(sr, si, cfg.magscalar));
+	wave_lds_sync();			// the region is rewritten by the next round
+	const uint64_t t_out = MIFSK_CLOCK();
+	wcyc[0] += t_mid - t_in;
+	wcyc[1] += t_out - t_mid;
     }
-    if ( active )
-	lds->mags[buf][w] = make_float2(band_mag(mr, mi, cfg.magscalar),
-					band_mag(sr, si, cfg.magscalar));
-    const uint64_t t_out = MIFSK_CLOCK();
-    wcyc[0] += t_mid - t_in;
-    wcyc[1] += t_out - t_mid;
 }
 
 // The worker waves' whole life.  A real (non-inlined) function on purpose: it
@@ -1525,12 +1536,20 @@ __device__ __forceinline__ void worker_main( const DevCfg *__restrict__ cfgp,
 	    break;
 	if ( op == CMD_SCAN ) {
 	    scan_part<USE_SLAB>(cfg, tw, lds, cmd, x, N, slab_cap);
+	    // nothing is in flight after a SCAN: end the prefetch registers' live
+	    // ranges here so that they do not add to the pressure inside it
 	    pref_org4 = 0xFFFFFFFFu;
+#pragma unroll
+	    for ( int i = 0; i < STAGE_VEC; i++ )
+		pbuf[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 	} else if ( USE_SLAB && op == CMD_LATTICE ) {
-	    if ( cfg.lat_linear )
-		worker_lattice_linear(cfg, tw, lds, cmd, x, N, region_floats, lat_frames,
-				      wkr, pbuf, pref_org4, wcyc);
-	    else
+	    if ( cfg.lat_linear ) {
+		// rounds of lat_frames frames (what the regions hold)
+		const uint32_t total = cmd->frames;
+		for ( uint32_t done = 0; done < total; done += lat_frames )
+		    worker_lattice_linear(cfg, tw, lds, cmd, x, N, region_floats, lat_frames,
+					  wkr, done, pbuf, pref_org4, wcyc);
+	    } else
 		worker_lattice(cfg, tw, lds, cmd, x, N, region_floats, region_cap, lat_frames,
 			       wkr, pbuf, pref_org4, wcyc);
 	}
@@ -1549,8 +1568,8 @@ __device__ __forceinline__ void worker_main( const DevCfg *__restrict__ cfgp,
 template <bool USE_SLAB>
 __global__ __launch_bounds__(BLOCK, 4)
 void demod_kernel( const DevCfg *__restrict__ cfgp, const double *__restrict__ tw,
-	mifsk_demod_io io, uint32_t slab_cap, uint32_t lat_frames, uint32_t region_floats,
-	uint32_t region_cap )
+	mifsk_demod_io io, uint32_t slab_cap, uint32_t lat_frames, uint32_t lat_rounds,
+	uint32_t region_floats, uint32_t region_cap )
 {
     StreamLds *lds = reinterpret_cast<StreamLds *>(mifsk_smem);
     // the configuration lives in device memory (uniform -> scalar loads); it is
@@ -1569,7 +1588,7 @@ void demod_kernel( const DevCfg *__restrict__ cfgp, const double *__restrict__ t
 	// the serial chain is the critical path of the workgroup: let it win
 	// issue arbitration against the (throughput-bound) worker waves
 	__builtin_amdgcn_s_setprio(3);
-	master_loop<USE_SLAB>(cfg, tw, io, slab_cap, lat_frames, lds);
+	master_loop<USE_SLAB>(cfg, tw, io, slab_cap, lat_frames * lat_rounds, lds);
     } else {
 	worker_main<USE_SLAB>(cfgp, tw, lds, io.d_samples + (size_t)blockIdx.x * io.stream_stride,
 			      io.d_nsamples ? io.d_nsamples[blockIdx.x] : io.nsamples,
@@ -1678,6 +1697,17 @@ int launch_demod_batch( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_
 	lat_frames--;
     }
 
+    // the master scores `lat_rounds` rounds at once (only the linear worker
+    // iterates rounds): halves the per-frame cost of everything that is paid
+    // per batch -- the confidence pass, the barrier, the command hand-off
+    uint32_t lat_rounds = 1;
+    if ( lat_frames && cfg.lat_linear ) {
+	lat_rounds = 2;
+	while ( lat_rounds > 1 && ( lat_frames * lat_rounds > P_CAP
+				    || lat_frames * lat_rounds * cfg.n_bits > W_CAP ) )
+	    lat_rounds--;
+    }
+
     uint32_t slab_cap = 0;
     size_t slab_floats = 0;
     bool use_slab = true;
@@ -1709,11 +1739,11 @@ int launch_demod_batch( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_
 	if ( e != hipSuccess )
 	    return hip_rc(e);
 	hipLaunchKernelGGL(demod_kernel<true>, dim3((unsigned)io.nstreams), dim3(BLOCK),
-			   lds_bytes, st, d_cfg, d_tw, io, slab_cap, lat_frames,
+			   lds_bytes, st, d_cfg, d_tw, io, slab_cap, lat_frames, lat_rounds,
 			   (uint32_t)region_floats, region_cap);
     } else {
 	hipLaunchKernelGGL(demod_kernel<false>, dim3((unsigned)io.nstreams), dim3(BLOCK),
-			   kLdsHeader + 16, st, d_cfg, d_tw, io, 0u, 0u, 0u, 0u);
+			   kLdsHeader + 16, st, d_cfg, d_tw, io, 0u, 0u, 1u, 0u, 0u);
     }
     return hip_rc(hipGetLastError());
 }
