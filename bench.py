@@ -90,7 +90,7 @@ def cpu_baselines(host, payloads, gpu_bytes, gpu_nbytes):
 
     # (2) the reference program itself (unmodified src/*.c + shims) on a bounded sample
     if O.have_ref():
-        nref = 24
+        nref = min(384, host.shape[0])		# ~13 s of single-core work
         tmp = tempfile.mkdtemp(prefix="mifsk-bench-")
         paths = []
         for i in range(nref):
@@ -120,6 +120,21 @@ def cpu_baselines(host, payloads, gpu_bytes, gpu_nbytes):
     else:
         out["cpu_baseline"] = dict(out["cpu_port"])
     return out
+
+
+def hbm_traffic():
+    """HBM bytes per kernel launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate passes, FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950
+    note), as recorded in profiles/ by tools/profile_round.sh for this workload; None
+    when no such record is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        return {"bytes_per_launch": rec["hbm_bytes_per_launch"], "source": "profiles/r01_hbm_traffic.json",
+                "fetch_size_kb_raw": rec["fetch_size_kb_raw"], "write_size_kb_raw": rec["write_size_kb_raw"]}
+    except Exception:
+        return None
 
 
 def main():
@@ -259,7 +274,7 @@ def main():
                        "sharding": "independent streams per rank, decoded bytes gathered to "
                                    "rank 0 over RCCL" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": hbm_traffic(),
                          "kernel": "mifsk::demod_kernel<true>",
                          "kernel_ms_avg": kavg * 1e3, "kernel_ms_min": float(np.min(kernel_ms)),
                          "algorithmic_bytes_per_launch": nstreams * NSAMPLES * 4.0},
