@@ -315,6 +315,8 @@ void find_frame_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 // predicate is handed to the general path, which recomputes from the samples.
 // ---------------------------------------------------------------------------
 
+__device__ __forceinline__ void lds_barrier();
+
 constexpr int NWORKERS = 3;
 constexpr int LAT_LANES = NWORKERS * 64;	// bit windows per lattice batch
 
@@ -600,10 +602,20 @@ __device__ __forceinline__ void scan_part( const DevCfg &cfg, const double *__re
     const uint32_t row_org = cmd->row_org;
     if ( USE_SLAB && cmd->stage ) {
 	par_stage(cfg, lds, x, N, slab_cap, row_org);
-	__syncthreads();
+	lds_barrier();
     }
     par_correlate<USE_SLAB>(cfg, tw, lds, x, N, row_org, nq);
-    __syncthreads();
+    lds_barrier();
+}
+
+// Workgroup barrier that orders LDS only.  __syncthreads() also drains vmcnt,
+// i.e. it would make every wave wait for its outstanding GLOBAL loads (the
+// workers' register prefetch, the master's cache-warming loads) at every batch.
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 // Make this wave's LDS writes visible to its other lanes.  LDS operations of one
@@ -798,9 +810,6 @@ struct Master {
 	  lat_batch(lf), lane(threadIdx.x), inflight(false), inflight_anchor(0),
 	  inflight_frames(0), inflight_buf(0), seq(0) {}
 
-    // the slot for the command that the NEXT barrier publishes
-    __device__ __forceinline__ StreamLds::Cmd *next_cmd() { return &lds->cmd[seq & 1u]; }
-
     // frames of a lattice batch anchored at `anchor` that still start inside the stream
     __device__ __forceinline__ uint32_t lattice_frames_at( uint32_t anchor ) const
     {
@@ -834,7 +843,7 @@ struct Master {
 	if ( !frames )
 	    return;
 	publish_lattice(anchor, frames, 0);
-	__syncthreads();			// workers pick the command up
+	lds_barrier();			// workers pick the command up
 	seq++;
     }
 
@@ -846,7 +855,7 @@ struct Master {
 	const uint32_t next = anchor + frames * cfg.lock_advance;
 	publish_lattice(next, lattice_frames_at(next), buf ^ 1u);
 	const uint64_t t_w = MIFSK_CLOCK();
-	__syncthreads();			// batch `anchor` is complete in mags[buf]
+	lds_barrier();			// batch `anchor` is complete in mags[buf]
 	seq++;
 	const uint64_t t_c = MIFSK_CLOCK();
 	cyc_wait += t_c - t_w;
@@ -900,7 +909,7 @@ struct Master {
 	n_batches++;
 	n_positions += nq;
 	const uint64_t t_par = MIFSK_CLOCK();
-	__syncthreads();			// command (and c_pos[]) published
+	lds_barrier();			// command (and c_pos[]) published
 	seq++;
 	scan_part<USE_SLAB>(cfg, tw, lds, c, x, N, slab_cap);
 	const uint64_t t_conf = MIFSK_CLOCK();
@@ -1393,7 +1402,7 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 	}
 	ctx.next_cmd()->op = CMD_EXIT;
     }
-    __syncthreads();				// releases the workers with "exit"
+    lds_barrier();				// releases the workers with "exit"
 }
 
 // LATTICE, linear variant (cfg.lat_linear): the bit length, every bit offset and
@@ -1528,7 +1537,7 @@ __device__ __forceinline__ void worker_main( const DevCfg *__restrict__ cfgp,
     uint64_t wcyc[3] = { 0, 0, 0 };
     for ( uint32_t seq = 0; ; seq++ ) {
 	const uint64_t t_b = MIFSK_CLOCK();
-	__syncthreads();			// command number `seq` has been published
+	lds_barrier();			// command number `seq` has been published
 	wcyc[2] += MIFSK_CLOCK() - t_b;
 	const StreamLds::Cmd *cmd = &lds->cmd[seq & 1u];
 	const uint32_t op = cmd->op;
@@ -1582,7 +1591,7 @@ void demod_kernel( const DevCfg *__restrict__ cfgp, const double *__restrict__ t
 	lds->c_q = 0;
 	lds->c_kind = 0;
     }
-    __syncthreads();
+    lds_barrier();
 
     if ( threadIdx.x < 64 ) {
 	// the serial chain is the critical path of the workgroup: let it win
