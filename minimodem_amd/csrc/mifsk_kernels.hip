@@ -610,7 +610,7 @@ __device__ __forceinline__ void scan_part( const DevCfg &cfg, const double *__re
 
 // Workgroup barrier that orders LDS only.  __syncthreads() also drains vmcnt,
 // i.e. it would make every wave wait for its outstanding GLOBAL loads (the
-// workers' register prefetch, the master's cache-warming loads) at every batch.
+// workers' register prefetch) at every batch.
 __device__ __forceinline__ void lds_barrier()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -809,6 +809,9 @@ struct Master {
 	: cfg(c), tw(t), x(xs), N(n), lds(l), slab_cap(cap), slab_lo(0), slab_hi(0),
 	  lat_batch(lf), lane(threadIdx.x), inflight(false), inflight_anchor(0),
 	  inflight_frames(0), inflight_buf(0), seq(0) {}
+
+    // the slot for the command that the NEXT barrier publishes
+    __device__ __forceinline__ StreamLds::Cmd *next_cmd() { return &lds->cmd[seq & 1u]; }
 
     // frames of a lattice batch anchored at `anchor` that still start inside the stream
     __device__ __forceinline__ uint32_t lattice_frames_at( uint32_t anchor ) const
