@@ -35,9 +35,6 @@
 
 // cycle timers for tools/counters.py; off in the production build because
 // each s_memtime read costs the serial wave a round trip
-#ifndef MIFSK_ABL
-#define MIFSK_ABL 0
-#endif
 #ifdef MIFSK_PROFILE
 #define MIFSK_CLOCK() clock64()
 #else
@@ -60,14 +57,6 @@ constexpr int W_CAP = 448;	// bit windows per batch (LDS scratch)
 // host, tests/test_host_math.py); f64 sqrt on gfx950 is correctly rounded.
 __device__ __forceinline__ float band_mag( double re, double im, float scalar )
 {
-#if MIFSK_ABL == 1
-    {	// additive ablation: the same work once more, result kept alive but unused
-	const float fr2 = (float)( re * 1.0000001 ), fi2 = (float)im;
-	const double s2 = (double)fr2 * (double)fr2 + (double)fi2 * (double)fi2;
-	float dummy = (float)sqrt(s2) * scalar;
-	asm volatile("" :: "v"(dummy));
-    }
-#endif
     const float fr = (float)re, fi = (float)im;
     const double s = (double)fr * (double)fr + (double)fi * (double)fi;
     return (float)sqrt(s) * scalar;
@@ -721,17 +710,6 @@ __device__ __forceinline__ void worker_lattice( const DevCfg &cfg, const double 
 		d[1 + ( r + 1 >= B ? skew : 0u )] = sv.y;
 		d[2 + ( r + 2 >= B ? skew : 0u )] = sv.z;
 		d[3 + ( r + 3 >= B ? skew : 0u )] = sv.w;
-#if MIFSK_ABL == 3
-		{   // additive ablation: the same address arithmetic and stores once more
-		    uint32_t r2 = r, q2 = q;
-		    asm volatile("" : "+v"(r2), "+v"(q2));
-		    float *d2 = region + ( first - head ) + q2 * skew;
-		    d2[0] = sv.x;
-		    d2[1 + ( r2 + 1 >= B ? skew : 0u )] = sv.y;
-		    d2[2 + ( r2 + 2 >= B ? skew : 0u )] = sv.z;
-		    d2[3 + ( r2 + 3 >= B ? skew : 0u )] = sv.w;
-		}
-#endif
 	    } else if ( v < nvec ) {
 		store4_skewed(cfg, region, region_cap, first, head, pbuf[i], org4 + first, N);
 	    }
@@ -759,12 +737,6 @@ __device__ __forceinline__ void worker_lattice( const DevCfg &cfg, const double 
 	for ( int i = 0; i < STAGE_VEC; i++ ) {
 	    const uint32_t v = i * 64 + lane;
 	    pbuf[i] = load4_raw(x, norg4 + ( v << 2 ), N);
-#if MIFSK_ABL == 6
-	    {
-		float4 extra = load4_raw(x, norg4 + ( v << 2 ) + 8192u, N);
-		asm volatile("" :: "v"(extra.x), "v"(extra.y), "v"(extra.z), "v"(extra.w));
-	    }
-#endif
 	}
 	pref_org4 = norg4;
     }
@@ -772,10 +744,6 @@ __device__ __forceinline__ void worker_lattice( const DevCfg &cfg, const double 
     const uint64_t t_mid = MIFSK_CLOCK();
 
     double acc[4];
-#if MIFSK_ABL == 4
-    correlate_window(cfg, tw, region, a - lo, active, acc);
-    asm volatile("" :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));
-#endif
     correlate_window(cfg, tw, region, a - lo, active, acc);
     if ( active )
 	lds->mags[buf][w] = make_float2(band_mag(acc[0], acc[1], cfg.magscalar),
@@ -864,19 +832,8 @@ struct Master {
 	cyc_wait += t_c - t_w;
 	n_lattice++;
 	if ( lane < frames ) {
-#if MIFSK_ABL == 2
-	    {
-		const FrameOut f2 = frame_confidence(&lds->mags[buf][lane * cfg.n_bits],
-						     cfg.req_mask[0] ^ 1u, cfg.req_val[0], cfg.n_bits);
-		asm volatile("" :: "v"(f2.conf), "v"(f2.ampl));
-	    }
-#endif
-#if MIFSK_ABL == 7 || MIFSK_ABL == 8
-	    FrameOut fo; fo.conf = 5.0f + lds->mags[buf][lane * cfg.n_bits].x * 1e-30f; fo.ampl = 1.0f; fo.bits = 0x2AB;
-#else
 	    const FrameOut fo = frame_confidence(&lds->mags[buf][lane * cfg.n_bits],
 						 cfg.req_mask[0], cfg.req_val[0], cfg.n_bits);
-#endif
 	    lds->c_conf[lane] = fo.conf;
 	    lds->c_ampl[lane] = fo.ampl;
 	    lds->c_bits[lane] = fo.bits;
@@ -1118,27 +1075,7 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 		float t = track_amplitude, pk = peak_confidence;
 		float sc = confidence_total, sa = amplitude_total;
 		float my_t = t, my_pk = pk, my_sc = sc, my_sa = sa;
-#if MIFSK_ABL == 5
-#if MIFSK_ABL == 8
-		for ( uint32_t k = 0; k < 1; k++ ) {
-#else
 		for ( uint32_t k = 0; k < K; k++ ) {
-#endif
-		    const float c = lane_bcast(cv, k);
-		    const float a = lane_bcast(av, k);
-		    const bool me = lane == k;
-		    my_t = me ? t : my_t; my_pk = me ? pk : my_pk; my_sc = me ? sc : my_sc; my_sa = me ? sa : my_sa;
-		    t = ( t + a ) / 2.0f; pk = pk < c ? c : pk; sc += c; sa += a;
-		}
-		asm volatile("" :: "v"(my_t), "v"(my_pk), "v"(my_sc), "v"(my_sa));
-		t = track_amplitude; pk = peak_confidence; sc = confidence_total; sa = amplitude_total;
-		my_t = t; my_pk = pk; my_sc = sc; my_sa = sa;
-#endif
-#if MIFSK_ABL == 8
-		for ( uint32_t k = 0; k < 1; k++ ) {
-#else
-		for ( uint32_t k = 0; k < K; k++ ) {
-#endif
 		    const float c = lane_bcast(cv, k);
 		    const float a = lane_bcast(av, k);
 		    const bool me = lane == k;
