@@ -1409,8 +1409,11 @@ __device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const 
 	    const uint32_t v = i * 64 + lane;
 	    const uint32_t vlast = i * 64 + 63u;
 	    float4 sv = pbuf[i];
-	    const bool interior = vlast < nvec && lo + ( vlast << 2 ) + 3 < N;	// uniform
-	    if ( !interior ) {
+	    // uniform: does any lane's vector reach the end of the stream?  (Vectors
+	    // beyond nvec are simply not stored; only the stream tail is re-read.)
+	    const uint32_t elast = lo + ( vlast << 2 ) + 3u;
+	    const bool tail = elast >= N || elast < lo;
+	    if ( tail ) {
 		const uint32_t e = lo + ( v << 2 );
 		sv.x = ( e < N ) ? x[e] : 0.0f;
 		sv.y = ( e + 1 < N && e + 1 > e ) ? x[e + 1] : 0.0f;
