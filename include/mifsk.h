@@ -225,7 +225,7 @@ typedef struct mifsk_demod_io {
 } mifsk_demod_io;
 
 /* per-stream work counters (diagnostics; cycle counts are s_memtime ticks) */
-#define MIFSK_NCOUNTERS		16
+#define MIFSK_NCOUNTERS		24
 #define MIFSK_CNT_ITERATIONS	0	/* passes through the general loop body  */
 #define MIFSK_CNT_BATCHES	1	/* candidate batches evaluated           */
 #define MIFSK_CNT_STAGES	2	/* LDS slab (re)loads                    */

@@ -34,11 +34,11 @@ SEARCH_DTYPE = np.dtype([("sample_offset", "<u8"), ("navail", "<u4"), ("try_firs
 RESULT_DTYPE = np.dtype([("bits", "<u8"), ("confidence", "<f4"), ("amplitude", "<f4"),
                          ("frame_start", "<u4"), ("n_positions", "<u4")])
 assert SEARCH_DTYPE.itemsize == 32 and RESULT_DTYPE.itemsize == 24
-NCOUNTERS = 16
+NCOUNTERS = 24
 COUNTER_NAMES = {0: "iterations", 1: "batches", 2: "stages", 3: "bulk_frames", 4: "refines",
                  5: "cache_hits", 6: "positions", 7: "lattice_batches", 8: "cyc_total",
                  9: "cyc_scan", 10: "cyc_wait", 11: "cyc_confidence", 12: "cyc_bulk", 13: "w_stage", 14: "w_correlate",
-                 15: "w_barrier"}
+                 15: "w_barrier", 16: "w_stage_wait", 17: "w_stage_store", 18: "w_stage_issue"}
 
 
 def build(force=False):

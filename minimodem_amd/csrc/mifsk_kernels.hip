@@ -651,7 +651,7 @@ __device__ __forceinline__ uint32_t wave_max_u32( uint32_t v )
 __device__ __forceinline__ void worker_lattice( const DevCfg &cfg, const double *__restrict__ tw, StreamLds *lds,
 	const StreamLds::Cmd *cmd, const float *__restrict__ x, uint32_t N,
 	uint32_t region_floats, uint32_t region_cap, uint32_t lat_frames, uint32_t wkr,
-	float4 (&pbuf)[STAGE_VEC], uint32_t &pref_org4, uint64_t (&wcyc)[3] )
+	float4 (&pbuf)[STAGE_VEC], uint32_t &pref_org4, uint64_t (&wcyc)[6] )
 {
     const uint64_t t_in = MIFSK_CLOCK();
     const uint32_t lane = threadIdx.x & 63u;
@@ -1368,7 +1368,7 @@ __device__ __forceinline__ float4 load4_unaligned( const float *__restrict__ x, 
 __device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const double *__restrict__ tw,
 	StreamLds *lds, const StreamLds::Cmd *cmd, const float *__restrict__ x, uint32_t N,
 	uint32_t region_floats, uint32_t lat_frames, uint32_t wkr, uint32_t done,
-	float4 (&pbuf)[STAGE_VEC], uint32_t &pref_org4, uint64_t (&wcyc)[3] )
+	float4 (&pbuf)[STAGE_VEC], uint32_t &pref_org4, uint64_t (&wcyc)[6] )
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_bits = cfg.n_bits, B = cfg.bit_nsamples;
@@ -1380,6 +1380,12 @@ __device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const 
     const uint32_t total = cmd->frames;
     {
 	const uint64_t t_in = MIFSK_CLOCK();
+#ifdef MIFSK_PROFILE
+	// split the staging time: waiting for the prefetched data / LDS stores / issue
+	__builtin_amdgcn_s_waitcnt(0x0F70);	// vmcnt(0) only (gfx9 encoding)
+	const uint64_t t_arrived = MIFSK_CLOCK();
+	wcyc[3] += t_arrived - t_in;
+#endif
 	const uint32_t frames = total - done < lat_frames ? total - done : lat_frames;
 	const uint32_t anchor = cmd->anchor + done * cfg.lock_advance;
 	const uint32_t nwin = frames * n_bits;
@@ -1404,25 +1410,36 @@ __device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const 
 	    for ( int i = 0; i < STAGE_VEC; i++ )
 		pbuf[i] = load4_unaligned(x, lo + ( ( i * 64 + lane ) << 2 ), N);
 	}
+	// Registers -> LDS.  The store address of vector i is a constant 1 KiB
+	// further on than that of vector i - 1 (an immediate offset, no address
+	// registers).  Vectors beyond nvec are simply not stored.  Only a round
+	// that reaches the end of the stream (uniform test) re-reads by element:
+	// load4_unaligned() fetched from a clamped address there.
+	float *lane_base = region + ( lane << 2 );
+	const uint32_t nvec_lane = nvec > lane ? nvec - lane : 0u;	// vector i stored iff 64 i < nvec_lane
+	const uint32_t elast = lo + ( ( 64u * STAGE_VEC ) << 2 );
+	if ( elast < N && elast >= lo ) {
 #pragma unroll
-	for ( int i = 0; i < STAGE_VEC; i++ ) {
-	    const uint32_t v = i * 64 + lane;
-	    const uint32_t vlast = i * 64 + 63u;
-	    float4 sv = pbuf[i];
-	    // uniform: does any lane's vector reach the end of the stream?  (Vectors
-	    // beyond nvec are simply not stored; only the stream tail is re-read.)
-	    const uint32_t elast = lo + ( vlast << 2 ) + 3u;
-	    const bool tail = elast >= N || elast < lo;
-	    if ( tail ) {
-		const uint32_t e = lo + ( v << 2 );
+	    for ( int i = 0; i < STAGE_VEC; i++ )
+		if ( (uint32_t)( i * 64 ) < nvec_lane )
+		    *reinterpret_cast<float4 *>(lane_base + i * 256) = pbuf[i];
+	} else {
+#pragma unroll
+	    for ( int i = 0; i < STAGE_VEC; i++ ) {
+		const uint32_t e = lo + ( ( i * 64 + lane ) << 2 );
+		float4 sv;
 		sv.x = ( e < N ) ? x[e] : 0.0f;
 		sv.y = ( e + 1 < N && e + 1 > e ) ? x[e + 1] : 0.0f;
 		sv.z = ( e + 2 < N && e + 2 > e ) ? x[e + 2] : 0.0f;
 		sv.w = ( e + 3 < N && e + 3 > e ) ? x[e + 3] : 0.0f;
+		if ( (uint32_t)( i * 64 ) < nvec_lane )
+		    *reinterpret_cast<float4 *>(lane_base + i * 256) = sv;
 	    }
-	    if ( v < nvec )
-		*reinterpret_cast<float4 *>(region + ( v << 2 )) = sv;
 	}
+#ifdef MIFSK_PROFILE
+	const uint64_t t_stored = MIFSK_CLOCK();
+	wcyc[4] += t_stored - t_arrived;
+#endif
 	// The same share of the next round (of this batch or the next), assuming
 	// the lattice goes on; issued unconditionally and with no control flow
 	// after it (see worker_lattice).  (A second, alternating register buffer
@@ -1437,6 +1454,9 @@ __device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const 
 	}
 	wave_lds_sync();
 	const uint64_t t_mid = MIFSK_CLOCK();
+#ifdef MIFSK_PROFILE
+	wcyc[5] += t_mid - t_stored;
+#endif
 
 	const float *p = region + ( a - lo );
 	double mr = 0.0, mi = 0.0, sr = 0.0, si = 0.0;
@@ -1477,7 +1497,7 @@ __device__ __forceinline__ void worker_main( const DevCfg *__restrict__ cfgp,
     for ( int i = 0; i < STAGE_VEC; i++ )
 	pbuf[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     uint32_t pref_org4 = 0xFFFFFFFFu;
-    uint64_t wcyc[3] = { 0, 0, 0 };
+    uint64_t wcyc[6] = { 0, 0, 0, 0, 0, 0 };
     for ( uint32_t seq = 0; ; seq++ ) {
 	const uint64_t t_b = MIFSK_CLOCK();
 	lds_barrier();			// command number `seq` has been published
@@ -1511,6 +1531,9 @@ __device__ __forceinline__ void worker_main( const DevCfg *__restrict__ cfgp,
 	counters[13] = wcyc[0];
 	counters[14] = wcyc[1];
 	counters[15] = wcyc[2];
+	counters[16] = wcyc[3];
+	counters[17] = wcyc[4];
+	counters[18] = wcyc[5];
     }
 #else
     (void)counters;

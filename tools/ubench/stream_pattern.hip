@@ -57,6 +57,10 @@ int main(int argc, char** argv)
         double bytes = (double)nstreams * (nsteps - nsteps % depth) * step * 4.0;
         printf("%-44s nw=%d ch=%d depth=%d delay=%d mis=%d : %.3f ms  %.2f TB/s\n", name, nw, ch, depth, delay, misalign, ms, bytes / ms / 1e9);
     };
+    if (argc > 1) {     // single configuration (for counter collection): delay = argv[1]
+        run("3 waves x 10 KB, depth 1", pattern<10,1>, 3, 10, 1, atoi(argv[1]), 0);
+        return 0;
+    }
     for (int delay : {0, 400, 1200, 2500}) {
         run("3 waves x 10 KB, depth 1", pattern<10,1>, 3, 10, 1, delay, 0);
         run("3 waves x 10 KB, depth 1, misaligned", pattern<10,1>, 3, 10, 1, delay, 1);
