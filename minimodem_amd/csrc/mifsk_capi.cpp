@@ -205,8 +205,9 @@ static int get_twiddles( mifsk_ctx *ctx, const TwKey &key, const double **d_out 
 	    return 0;
 	}
     // zero-padded to a multiple of 8 samples: the correlator consumes the
-    // table in chunks of 8 and fma(x, 0, acc) leaves acc unchanged
-    const size_t n = ( (size_t)key.bit_nsamples + 7 ) & ~(size_t)7;
+    // table in chunks of 8 and fma(x, 0, acc) leaves acc unchanged; 8 more
+    // because the software-pipelined loop fetches one half chunk ahead
+    const size_t n = ( ( (size_t)key.bit_nsamples + 7 ) & ~(size_t)7 ) + 8;
     std::vector<double> h(4 * ( n ? n : 8 ), 0.0);
     for ( unsigned i = 0; i < key.bit_nsamples; i++ ) {
 	twiddle(key.b_mark, i, key.fftsize, &h[4 * (size_t)i]);

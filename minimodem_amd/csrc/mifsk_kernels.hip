@@ -74,7 +74,7 @@ struct FrameOut {
 // reference's order (contraction is disabled for this file).  The magnitudes
 // are fetched from LDS eight at a time so that the loads (and, in the second
 // pass, the independent divisions) overlap; the running sums stay sequential.
-constexpr int CCH = 8;
+constexpr int CCH = 5;
 
 __device__ __forceinline__ FrameOut
 frame_confidence( const float2 *mags, uint64_t req_mask, uint64_t req_val, uint32_t n_bits )
@@ -989,6 +989,13 @@ struct StreamOut {
     size_t		fcap, ecap;
 };
 
+// v of the lane below (DPP wave_shr:1); lane 0 reads 0
+__device__ __forceinline__ float wave_shr1( float v )
+{
+    const int i = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, i, 0x138, 0xf, 0xf, false));
+}
+
 __device__ __forceinline__ float lane_bcast( float v, uint32_t src )
 {
     return __builtin_bit_cast(float,
@@ -1069,25 +1076,33 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 		const float cv = have ? lds->c_conf[e0 + lane] : 0.0f;
 		const float av = have ? lds->c_ampl[e0 + lane] : 0.0f;
 		// Replay the f32 state recurrences over all K candidates without
-		// branching; lane k keeps the state as it was BEFORE frame k.  The
-		// values recorded for frames up to the first rejected one do not
-		// depend on anything after it, so they are exact.
-		float t = track_amplitude, pk = peak_confidence;
-		float sc = confidence_total, sa = amplitude_total;
-		float my_t = t, my_pk = pk, my_sc = sc, my_sa = sa;
-		for ( uint32_t k = 0; k < K; k++ ) {
-		    const float c = lane_bcast(cv, k);
-		    const float a = lane_bcast(av, k);
-		    const bool me = lane == k;
-		    my_t = me ? t : my_t;
-		    my_pk = me ? pk : my_pk;
-		    my_sc = me ? sc : my_sc;
-		    my_sa = me ? sa : my_sa;
-		    t = ( t + a ) / 2.0f;			// minimodem.c:1391
-		    pk = pk < c ? c : pk;			// minimodem.c:1392-1393
-		    sc += c;					// minimodem.c:1397-1398
-		    sa += a;
+		// branching.  Lane k wants the state as it was BEFORE frame k:
+		//   S_0 = current state,  S_k = step(S_{k-1}, c_{k-1}, a_{k-1}).
+		// Every lane applies step() to its lower neighbour's state (DPP
+		// wave_shr:1) and that neighbour's (c, a); after j rounds lanes
+		// 0..j are final, so K - 1 rounds settle lanes 0..K-1.  Same f32
+		// operations in the same order as the scalar loop, no cross-lane
+		// reads through SGPRs.  Lane 0 (S_0) is never changed.
+		const float cp = wave_shr1(cv), ap = wave_shr1(av);
+		float my_t = track_amplitude, my_pk = peak_confidence;
+		float my_sc = confidence_total, my_sa = amplitude_total;
+		for ( uint32_t k = 1; k < K; k++ ) {
+		    const float pt = wave_shr1(my_t), ppk = wave_shr1(my_pk);
+		    const float psc = wave_shr1(my_sc), psa = wave_shr1(my_sa);
+		    const float nt = ( pt + ap ) / 2.0f;	// minimodem.c:1391
+		    const float npk = ppk < cp ? cp : ppk;	// minimodem.c:1392-1393
+		    const float nsc = psc + cp;			// minimodem.c:1397-1398
+		    const float nsa = psa + ap;
+		    my_t = lane ? nt : my_t;
+		    my_pk = lane ? npk : my_pk;
+		    my_sc = lane ? nsc : my_sc;
+		    my_sa = lane ? nsa : my_sa;
 		}
+		// ... and the state after frame k
+		const float t = ( my_t + av ) / 2.0f;
+		const float pk = my_pk < cv ? cv : my_pk;
+		const float sc = my_sc + cv;
+		const float sa = my_sa + av;
 		const bool ok = have
 		    && cv > 0.0f && cv >= cfg.search_limit	// fsk.c:492,499: first try ends the scan
 		    && !( cv < my_pk * 0.75f )			// minimodem.c:1278
@@ -1097,7 +1112,10 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 		const uint32_t n = bad ? (uint32_t)__ffsll((long long)bad) - 1u : K;
 		float track, peak, ctot, atot;
 		if ( n == K ) {
-		    track = t; peak = pk; ctot = sc; atot = sa;
+		    track = lane_bcast(t, K - 1u);
+		    peak = lane_bcast(pk, K - 1u);
+		    ctot = lane_bcast(sc, K - 1u);
+		    atot = lane_bcast(sa, K - 1u);
 		} else {
 		    track = lane_bcast(my_t, n);
 		    peak = lane_bcast(my_pk, n);
@@ -1365,6 +1383,79 @@ __device__ __forceinline__ float4 load4_unaligned( const float *__restrict__ x, 
     return make_float4(s.x, s.y, s.z, s.w);
 }
 
+// The correlation loop of the linear variant, software-pipelined over half
+// chunks: while the 16 FMAs of 4 samples issue, the twiddles (scalar cache) and
+// the samples (LDS) of the next 4 are in flight, so neither latency is exposed.
+// One asm statement with fixed registers, because a load whose result is only
+// valid after a LATER s_waitcnt cannot be expressed to the compiler: given
+// separate asm statements it is free to copy or spill the destination registers
+// in between (it did).  Same operations in the same order as MIFSK_FMA4 over
+// samples 0 .. 8 nchunks - 1; the table is zero-padded to whole chunks.
+//   s[34:35] running table pointer, s33 chunks left,
+//   s[36:67] / s[68:99] twiddles of the even / odd half chunk,
+//   v[110:113] / v[114:117] samples of the even / odd half chunk,
+//   v119 running LDS address, v[120:121] the sample as a double.
+typedef __attribute__((address_space(3))) const float lds_cfloat;
+
+#define MIFSK_ASM_FMA4(X, S0, S1, S2, S3)			\
+	"v_cvt_f64_f32_e32 v[120:121], " X "\n\t"		\
+	"v_fmac_f64_e32 %[mr], " S0 ", v[120:121]\n\t"		\
+	"v_fmac_f64_e32 %[mi], " S1 ", v[120:121]\n\t"		\
+	"v_fmac_f64_e32 %[sr], " S2 ", v[120:121]\n\t"		\
+	"v_fmac_f64_e32 %[si], " S3 ", v[120:121]\n\t"
+
+__device__ __forceinline__ void correlate_linear_asm( const double *tw, const float *p,
+	uint32_t nchunks, double &mr, double &mi, double &sr, double &si )
+{
+    const uint32_t tw_lo = (uint32_t)(uintptr_t)tw;
+    const uint32_t tw_hi = (uint32_t)( (uintptr_t)tw >> 32 );
+    const uint32_t addr = (uint32_t)(uintptr_t)(lds_cfloat *)p;
+    asm volatile(
+	"s_mov_b32 s34, %[tlo]\n\t"
+	"s_mov_b32 s35, %[thi]\n\t"
+	"s_mov_b32 s33, %[nch]\n\t"
+	"v_mov_b32_e32 v119, %[addr]\n\t"
+	"s_load_dwordx16 s[36:51], s[34:35], 0x0\n\t"
+	"s_load_dwordx16 s[52:67], s[34:35], 0x40\n\t"
+	"ds_read_b128 v[110:113], v119\n\t"
+	"1:\n\t"
+	"s_waitcnt lgkmcnt(0)\n\t"
+	"s_load_dwordx16 s[68:83], s[34:35], 0x80\n\t"
+	"s_load_dwordx16 s[84:99], s[34:35], 0xc0\n\t"
+	"ds_read_b128 v[114:117], v119 offset:16\n\t"
+	MIFSK_ASM_FMA4("v110", "s[36:37]", "s[38:39]", "s[40:41]", "s[42:43]")
+	MIFSK_ASM_FMA4("v111", "s[44:45]", "s[46:47]", "s[48:49]", "s[50:51]")
+	MIFSK_ASM_FMA4("v112", "s[52:53]", "s[54:55]", "s[56:57]", "s[58:59]")
+	MIFSK_ASM_FMA4("v113", "s[60:61]", "s[62:63]", "s[64:65]", "s[66:67]")
+	"s_add_u32 s34, s34, 0x100\n\t"
+	"s_addc_u32 s35, s35, 0\n\t"
+	"v_add_u32_e32 v119, 32, v119\n\t"
+	"s_sub_u32 s33, s33, 1\n\t"
+	"s_waitcnt lgkmcnt(0)\n\t"
+	"s_cmp_eq_u32 s33, 0\n\t"
+	"s_cbranch_scc1 2f\n\t"
+	"s_load_dwordx16 s[36:51], s[34:35], 0x0\n\t"
+	"s_load_dwordx16 s[52:67], s[34:35], 0x40\n\t"
+	"ds_read_b128 v[110:113], v119\n\t"
+	"2:\n\t"
+	MIFSK_ASM_FMA4("v114", "s[68:69]", "s[70:71]", "s[72:73]", "s[74:75]")
+	MIFSK_ASM_FMA4("v115", "s[76:77]", "s[78:79]", "s[80:81]", "s[82:83]")
+	MIFSK_ASM_FMA4("v116", "s[84:85]", "s[86:87]", "s[88:89]", "s[90:91]")
+	MIFSK_ASM_FMA4("v117", "s[92:93]", "s[94:95]", "s[96:97]", "s[98:99]")
+	"s_cmp_lg_u32 s33, 0\n\t"
+	"s_cbranch_scc1 1b\n\t"
+	: [mr] "+v"(mr), [mi] "+v"(mi), [sr] "+v"(sr), [si] "+v"(si)
+	: [tlo] "s"(tw_lo), [thi] "s"(tw_hi), [nch] "s"(nchunks), [addr] "v"(addr)
+	: "memory", "scc",
+	  "s33", "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45",
+	  "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58",
+	  "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71",
+	  "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84",
+	  "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97",
+	  "s98", "s99",
+	  "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v119", "v120", "v121");
+}
+
 __device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const double *__restrict__ tw,
 	StreamLds *lds, const StreamLds::Cmd *cmd, const float *__restrict__ x, uint32_t N,
 	uint32_t region_floats, uint32_t lat_frames, uint32_t wkr, uint32_t done,
@@ -1458,19 +1549,8 @@ __device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const 
 	wcyc[5] += t_mid - t_stored;
 #endif
 
-	const float *p = region + ( a - lo );
 	double mr = 0.0, mi = 0.0, sr = 0.0, si = 0.0;
-	for ( uint32_t n0 = 0; n0 < B; n0 += XCH ) {
-	    tw8 ta, tb, tc, td;
-	    twiddle_fetch(tw + 4 * (size_t)n0, ta, tb, tc, td);
-	    const float4 x0 = *reinterpret_cast<const float4 *>(p + n0);
-	    const float4 x1 = *reinterpret_cast<const float4 *>(p + n0 + 4);
-	    twiddle_wait();
-	    MIFSK_FMA4(x0.x, ta, 0);  MIFSK_FMA4(x0.y, ta, 1);
-	    MIFSK_FMA4(x0.z, tb, 0);  MIFSK_FMA4(x0.w, tb, 1);
-	    MIFSK_FMA4(x1.x, tc, 0);  MIFSK_FMA4(x1.y, tc, 1);
-	    MIFSK_FMA4(x1.z, td, 0);  MIFSK_FMA4(x1.w, td, 1);
-	}
+	correlate_linear_asm(tw, region + ( a - lo ), ( B + XCH - 1 ) / XCH, mr, mi, sr, si);
 	if ( active )
 	    lds->mags[buf][done * n_bits + w] = make_float2(band_mag(mr, mi, cfg.magscalar),
 							   band_mag(sr, si, cfg.magscalar));
