@@ -1459,6 +1459,7 @@ __device__ __forceinline__ void correlate_linear_asm( const double *tw, const fl
 __device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const double *__restrict__ tw,
 	StreamLds *lds, const StreamLds::Cmd *cmd, const float *__restrict__ x, uint32_t N,
 	uint32_t region_floats, uint32_t lat_frames, uint32_t wkr, uint32_t done,
+	uint32_t rel_lane, uint32_t safe_limit,
 	float4 (&pbuf)[STAGE_VEC], uint32_t &pref_org4, uint64_t (&wcyc)[6] )
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -1486,20 +1487,33 @@ __device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const 
 	    return;				// nothing for this wave this round (uniform)
 	}
 	const bool active = w < nwin;
-	const uint32_t wc = active ? w : nwin - 1u;	// idle lanes shadow the last window
-	const uint32_t f = udiv_magic(wc, n_bits, cfg.nbits_magic);
-	const uint32_t k = wc - f * n_bits;
-	const uint32_t a = anchor + f * cfg.lock_advance + cfg.bit_offset[k];
-	const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
-	const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)a, 63) + B;
+	// window start: rel_lane = f * lock_advance + bit_offset[k] for window
+	// w = f * n_bits + k is the same in every round (worker_main); idle
+	// lanes shadow the first window
+	const uint32_t last = nwin - wkr * 64u > 64u ? 63u : nwin - wkr * 64u - 1u;	// uniform
+	const uint32_t a1 = anchor + rel_lane;
+	const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)a1);
+	const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)a1, (int)last) + B;
+	const uint32_t a = active ? a1 : lo;
 	// + XCH: the last chunk of the last window may run past it (zero twiddles)
 	const uint32_t nvec = ( hi - lo + XCH + 3 ) >> 2;
 
+	// Raw loads of one round: 64 * STAGE_VEC consecutive float4 from sample
+	// `from`, whatever the round really needs -- no per-lane bounds logic, the
+	// addresses differ by immediates.  `safe_limit` (>= N) is how far this
+	// row may be over-read without leaving the batch's allocation; a round
+	// that would cross it is fetched from sample 0 instead and its data never
+	// used (it reaches the end of the stream, so it is re-read by element).
+	constexpr uint32_t kRoundFloats = 64u * STAGE_VEC * 4u;
 	if ( pref_org4 != lo ) {
 	    // nothing usable in flight: fetch this round now
+	    const bool ok = lo <= safe_limit - kRoundFloats;	// (the master guarantees safe_limit >= kRoundFloats)
+	    const float *pb = x + ( ok ? lo : 0u ) + ( lane << 2 );
 #pragma unroll
-	    for ( int i = 0; i < STAGE_VEC; i++ )
-		pbuf[i] = load4_unaligned(x, lo + ( ( i * 64 + lane ) << 2 ), N);
+	    for ( int i = 0; i < STAGE_VEC; i++ ) {
+		const float4_u sv = *reinterpret_cast<const float4_u *>(pb + i * 256);
+		pbuf[i] = make_float4(sv.x, sv.y, sv.z, sv.w);
+	    }
 	}
 	// Registers -> LDS.  The store address of vector i is a constant 1 KiB
 	// further on than that of vector i - 1 (an immediate offset, no address
@@ -1508,8 +1522,8 @@ __device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const 
 	// load4_unaligned() fetched from a clamped address there.
 	float *lane_base = region + ( lane << 2 );
 	const uint32_t nvec_lane = nvec > lane ? nvec - lane : 0u;	// vector i stored iff 64 i < nvec_lane
-	const uint32_t elast = lo + ( ( 64u * STAGE_VEC ) << 2 );
-	if ( elast < N && elast >= lo ) {
+	const uint32_t elast = lo + kRoundFloats;
+	if ( elast <= N && elast >= lo ) {
 #pragma unroll
 	    for ( int i = 0; i < STAGE_VEC; i++ )
 		if ( (uint32_t)( i * 64 ) < nvec_lane )
@@ -1538,10 +1552,14 @@ __device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const 
 	// four workgroups per CU impose: it spills into the hot loop.)
 	{
 	    const uint32_t nlo = lo + lat_frames * cfg.lock_advance;
+	    const bool ok = nlo >= lo && nlo <= safe_limit - kRoundFloats;
+	    const float *pb = x + ( ok ? nlo : 0u ) + ( lane << 2 );
 #pragma unroll
-	    for ( int i = 0; i < STAGE_VEC; i++ )
-		pbuf[i] = load4_unaligned(x, nlo + ( ( i * 64 + lane ) << 2 ), N);
-	    pref_org4 = nlo;
+	    for ( int i = 0; i < STAGE_VEC; i++ ) {
+		const float4_u sv = *reinterpret_cast<const float4_u *>(pb + i * 256);
+		pbuf[i] = make_float4(sv.x, sv.y, sv.z, sv.w);
+	    }
+	    pref_org4 = ok ? nlo : 0xFFFFFFFFu;
 	}
 	wave_lds_sync();
 	const uint64_t t_mid = MIFSK_CLOCK();
@@ -1568,10 +1586,17 @@ template <bool USE_SLAB>
 __device__ __forceinline__ void worker_main( const DevCfg *__restrict__ cfgp,
 	const double *__restrict__ tw, StreamLds *lds, const float *__restrict__ x, uint32_t N,
 	uint32_t slab_cap, uint32_t lat_frames, uint32_t region_floats, uint32_t region_cap,
-	uint64_t *counters )
+	uint32_t safe_limit, uint64_t *counters )
 {
     const DevCfg &cfg = *cfgp;
     const uint32_t wkr = ( threadIdx.x >> 6 ) - 1u;
+    // linear LATTICE: start of this lane's window relative to the round's anchor
+    uint32_t rel_lane = 0;
+    if ( USE_SLAB && cfg.lat_linear ) {
+	const uint32_t w = wkr * 64u + ( threadIdx.x & 63u );
+	const uint32_t f = udiv_magic(w, cfg.n_bits, cfg.nbits_magic);
+	rel_lane = f * cfg.lock_advance + cfg.bit_offset[( w - f * cfg.n_bits ) & 63u];
+    }
     float4 pbuf[STAGE_VEC];
 #pragma unroll
     for ( int i = 0; i < STAGE_VEC; i++ )
@@ -1600,7 +1625,7 @@ __device__ __forceinline__ void worker_main( const DevCfg *__restrict__ cfgp,
 		const uint32_t total = cmd->frames;
 		for ( uint32_t done = 0; done < total; done += lat_frames )
 		    worker_lattice_linear(cfg, tw, lds, cmd, x, N, region_floats, lat_frames,
-					  wkr, done, pbuf, pref_org4, wcyc);
+					  wkr, done, rel_lane, safe_limit, pbuf, pref_org4, wcyc);
 	    } else
 		worker_lattice(cfg, tw, lds, cmd, x, N, region_floats, region_cap, lat_frames,
 			       wkr, pbuf, pref_org4, wcyc);
@@ -1639,6 +1664,17 @@ void demod_kernel( const DevCfg *__restrict__ cfgp, const double *__restrict__ t
     }
     lds_barrier();
 
+    // How far this stream's row may be over-read (in samples from its start)
+    // without leaving the batch: the rows after it, or for the last row its own
+    // length.  The linear LATTICE fetches whole rounds of 64 * STAGE_VEC float4
+    // with no per-lane bounds logic and needs at least one round of room.
+    const uint32_t n_own = io.d_nsamples ? io.d_nsamples[blockIdx.x] : io.nsamples;
+    const uint64_t rows_after = (uint64_t)( io.nstreams - 1 - (int)blockIdx.x ) * io.stream_stride;
+    const uint32_t safe_limit = rows_after == 0 ? n_own
+			      : rows_after > 0xFFFF0000ull ? 0xFFFF0000u : (uint32_t)rows_after;
+    if ( cfg.lat_linear && safe_limit < 64u * STAGE_VEC * 4u )
+	lat_frames = 0;
+
     if ( threadIdx.x < 64 ) {
 	// the serial chain is the critical path of the workgroup: let it win
 	// issue arbitration against the (throughput-bound) worker waves
@@ -1646,8 +1682,7 @@ void demod_kernel( const DevCfg *__restrict__ cfgp, const double *__restrict__ t
 	master_loop<USE_SLAB>(cfg, tw, io, slab_cap, lat_frames * lat_rounds, lds);
     } else {
 	worker_main<USE_SLAB>(cfgp, tw, lds, io.d_samples + (size_t)blockIdx.x * io.stream_stride,
-			      io.d_nsamples ? io.d_nsamples[blockIdx.x] : io.nsamples,
-			      slab_cap, lat_frames, region_floats, region_cap,
+			      n_own, slab_cap, lat_frames, region_floats, region_cap, safe_limit,
 			      io.d_counters ? io.d_counters + (size_t)blockIdx.x * MIFSK_NCOUNTERS : nullptr);
     }
 }
