@@ -36,9 +36,9 @@
 // cycle timers for tools/counters.py; off in the production build because
 // each s_memtime read costs the serial wave a round trip
 #ifdef MIFSK_PROFILE
-#define MIFSK_CLOCK() clock64()
+#define MIFSK_CLOCK() ((uint32_t)clock64())
 #else
-#define MIFSK_CLOCK() 0ULL
+#define MIFSK_CLOCK() 0u
 #endif
 
 namespace mifsk {
@@ -651,9 +651,9 @@ __device__ __forceinline__ uint32_t wave_max_u32( uint32_t v )
 __device__ __forceinline__ void worker_lattice( const DevCfg &cfg, const double *__restrict__ tw, StreamLds *lds,
 	const StreamLds::Cmd *cmd, const float *__restrict__ x, uint32_t N,
 	uint32_t region_floats, uint32_t region_cap, uint32_t lat_frames, uint32_t wkr,
-	float4 (&pbuf)[STAGE_VEC], uint32_t &pref_org4, uint64_t (&wcyc)[6] )
+	float4 (&pbuf)[STAGE_VEC], uint32_t &pref_org4, uint32_t (&wcyc)[3] )
 {
-    const uint64_t t_in = MIFSK_CLOCK();
+    const uint32_t t_in = MIFSK_CLOCK();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_bits = cfg.n_bits, B = cfg.bit_nsamples;
     const uint32_t anchor = cmd->anchor;
@@ -741,14 +741,14 @@ __device__ __forceinline__ void worker_lattice( const DevCfg &cfg, const double 
 	pref_org4 = norg4;
     }
     wave_lds_sync();
-    const uint64_t t_mid = MIFSK_CLOCK();
+    const uint32_t t_mid = MIFSK_CLOCK();
 
     double acc[4];
     correlate_window(cfg, tw, region, a - lo, active, acc);
     if ( active )
 	lds->mags[buf][w] = make_float2(band_mag(acc[0], acc[1], cfg.magscalar),
 					band_mag(acc[2], acc[3], cfg.magscalar));
-    const uint64_t t_out = MIFSK_CLOCK();
+    const uint32_t t_out = MIFSK_CLOCK();
     wcyc[0] += t_mid - t_in;
     wcyc[1] += t_out - t_mid;
 }
@@ -770,7 +770,7 @@ struct Master {
     uint32_t		seq;		// barriers that published a command so far
     // work counters (written out only when the caller asked for them)
     uint32_t		n_batches = 0, n_stages = 0, n_hits = 0, n_positions = 0, n_lattice = 0;
-    uint64_t		cyc_par = 0, cyc_conf = 0, cyc_wait = 0;
+    uint32_t		cyc_par = 0, cyc_conf = 0, cyc_wait = 0;
 
     __device__ __forceinline__ Master( const DevCfg &c, const double *t, const float *xs,
 	    uint32_t n, StreamLds *l, uint32_t cap, uint32_t lf )
@@ -825,10 +825,10 @@ struct Master {
 	const uint32_t anchor = inflight_anchor, frames = inflight_frames, buf = inflight_buf;
 	const uint32_t next = anchor + frames * cfg.lock_advance;
 	publish_lattice(next, lattice_frames_at(next), buf ^ 1u);
-	const uint64_t t_w = MIFSK_CLOCK();
+	const uint32_t t_w = MIFSK_CLOCK();
 	lds_barrier();			// batch `anchor` is complete in mags[buf]
 	seq++;
-	const uint64_t t_c = MIFSK_CLOCK();
+	const uint32_t t_c = MIFSK_CLOCK();
 	cyc_wait += t_c - t_w;
 	n_lattice++;
 	if ( lane < frames ) {
@@ -868,11 +868,11 @@ struct Master {
 	inflight = false;		// the barrier below also retires any batch in flight
 	n_batches++;
 	n_positions += nq;
-	const uint64_t t_par = MIFSK_CLOCK();
+	const uint32_t t_par = MIFSK_CLOCK();
 	lds_barrier();			// command (and c_pos[]) published
 	seq++;
 	scan_part<USE_SLAB>(cfg, tw, lds, c, x, N, slab_cap);
-	const uint64_t t_conf = MIFSK_CLOCK();
+	const uint32_t t_conf = MIFSK_CLOCK();
 	cyc_par += t_conf - t_par;
 	if ( lane < nq ) {
 	    const FrameOut f = frame_confidence(&lds->mags[0][lane * cfg.n_bits],
@@ -1035,8 +1035,8 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
     uint32_t n_out_frames = 0, n_out_bytes = 0, n_out_eps = 0, ep_first = 0;
     uint32_t status = 0;
     uint32_t n_iter = 0, n_bulk = 0, n_refine = 0;
-    uint64_t cyc_bulk = 0;
-    const uint64_t t_start = MIFSK_CLOCK();
+    uint32_t cyc_bulk = 0;
+    const uint32_t t_start = MIFSK_CLOCK();
 
     const ZigZag zc0(cfg.try_first[0], cfg.try_max[0], cfg.try_step[0]);
     const ZigZag zc1(cfg.try_first[1], cfg.try_max[1], cfg.try_step[1]);
@@ -1054,7 +1054,7 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 	// that fails any of them falls through to the general path below.
 	// ------------------------------------------------------------------
 	if ( carrier && advance && advance <= N - base ) {
-	    const uint64_t t_bulk = MIFSK_CLOCK();
+	    const uint32_t t_bulk = MIFSK_CLOCK();
 	    const uint32_t first = cfg.try_first[1];
 	    const uint32_t nb = base + advance;		// cursor of the next iteration
 	    const uint32_t p = nb + first;
@@ -1460,7 +1460,7 @@ __device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const 
 	StreamLds *lds, const StreamLds::Cmd *cmd, const float *__restrict__ x, uint32_t N,
 	uint32_t region_floats, uint32_t lat_frames, uint32_t wkr, uint32_t done,
 	uint32_t rel_lane, uint32_t safe_limit,
-	float4 (&pbuf)[STAGE_VEC], uint32_t &pref_org4, uint64_t (&wcyc)[6] )
+	float4 (&pbuf)[STAGE_VEC], uint32_t &pref_org4, uint32_t (&wcyc)[3] )
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_bits = cfg.n_bits, B = cfg.bit_nsamples;
@@ -1471,13 +1471,7 @@ __device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const 
     // continues from one round into the next, and so does the prefetch.
     const uint32_t total = cmd->frames;
     {
-	const uint64_t t_in = MIFSK_CLOCK();
-#ifdef MIFSK_PROFILE
-	// split the staging time: waiting for the prefetched data / LDS stores / issue
-	__builtin_amdgcn_s_waitcnt(0x0F70);	// vmcnt(0) only (gfx9 encoding)
-	const uint64_t t_arrived = MIFSK_CLOCK();
-	wcyc[3] += t_arrived - t_in;
-#endif
+	const uint32_t t_in = MIFSK_CLOCK();
 	const uint32_t frames = total - done < lat_frames ? total - done : lat_frames;
 	const uint32_t anchor = cmd->anchor + done * cfg.lock_advance;
 	const uint32_t nwin = frames * n_bits;
@@ -1541,10 +1535,6 @@ __device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const 
 		    *reinterpret_cast<float4 *>(lane_base + i * 256) = sv;
 	    }
 	}
-#ifdef MIFSK_PROFILE
-	const uint64_t t_stored = MIFSK_CLOCK();
-	wcyc[4] += t_stored - t_arrived;
-#endif
 	// The same share of the next round (of this batch or the next), assuming
 	// the lattice goes on; issued unconditionally and with no control flow
 	// after it (see worker_lattice).  (A second, alternating register buffer
@@ -1562,10 +1552,7 @@ __device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const 
 	    pref_org4 = ok ? nlo : 0xFFFFFFFFu;
 	}
 	wave_lds_sync();
-	const uint64_t t_mid = MIFSK_CLOCK();
-#ifdef MIFSK_PROFILE
-	wcyc[5] += t_mid - t_stored;
-#endif
+	const uint32_t t_mid = MIFSK_CLOCK();
 
 	double mr = 0.0, mi = 0.0, sr = 0.0, si = 0.0;
 	correlate_linear_asm(tw, region + ( a - lo ), ( B + XCH - 1 ) / XCH, mr, mi, sr, si);
@@ -1573,7 +1560,7 @@ __device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const 
 	    lds->mags[buf][done * n_bits + w] = make_float2(band_mag(mr, mi, cfg.magscalar),
 							   band_mag(sr, si, cfg.magscalar));
 	wave_lds_sync();			// the region is rewritten by the next round
-	const uint64_t t_out = MIFSK_CLOCK();
+	const uint32_t t_out = MIFSK_CLOCK();
 	wcyc[0] += t_mid - t_in;
 	wcyc[1] += t_out - t_mid;
     }
@@ -1602,9 +1589,9 @@ __device__ __forceinline__ void worker_main( const DevCfg *__restrict__ cfgp,
     for ( int i = 0; i < STAGE_VEC; i++ )
 	pbuf[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     uint32_t pref_org4 = 0xFFFFFFFFu;
-    uint64_t wcyc[6] = { 0, 0, 0, 0, 0, 0 };
+    uint32_t wcyc[3] = { 0, 0, 0 };
     for ( uint32_t seq = 0; ; seq++ ) {
-	const uint64_t t_b = MIFSK_CLOCK();
+	const uint32_t t_b = MIFSK_CLOCK();
 	lds_barrier();			// command number `seq` has been published
 	wcyc[2] += MIFSK_CLOCK() - t_b;
 	const StreamLds::Cmd *cmd = &lds->cmd[seq & 1u];
@@ -1636,9 +1623,6 @@ __device__ __forceinline__ void worker_main( const DevCfg *__restrict__ cfgp,
 	counters[13] = wcyc[0];
 	counters[14] = wcyc[1];
 	counters[15] = wcyc[2];
-	counters[16] = wcyc[3];
-	counters[17] = wcyc[4];
-	counters[18] = wcyc[5];
     }
 #else
     (void)counters;

@@ -35,7 +35,7 @@ def main():
         col = c[:, idx]
         print("%-16s mean %12.1f  min %12.0f  max %12.0f" % (name, col.mean(), col.min(), col.max()))
     tot = c[:, 8].mean()
-    for idx in (9, 10, 11, 12, 13, 14, 15, 16, 17, 18):
+    for idx in (9, 10, 11, 12, 13, 14, 15):
         print("  %-14s %5.1f%% of kernel cycles" % (M.COUNTER_NAMES[idx], 100 * c[:, idx].mean() / tot))
 
 
