@@ -248,6 +248,51 @@ int mifsk_demod_batch( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
 int mifsk_demod_batch_host( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
 	const mifsk_demod_io *io );
 
+/* ---- host post-pass: frame bits -> text -------------------- */
+
+/* The databits decoders main() plugs in behind the search (databits.h:49-92:
+ * databits_decode_ascii8 / _baudot / _binary / _callerid / _uic_ground /
+ * _uic_train).  O(1) per frame, stateful (Baudot shift, caller-ID message
+ * buffer), byte-serial: host work over the frame bits the device gathered.
+ * One object = the decoder's static state in the reference. */
+typedef struct mifsk_databits mifsk_databits;
+
+int  mifsk_databits_create( mifsk_databits **out, int decoder /* enum mifsk_decoder */ );
+void mifsk_databits_destroy( mifsk_databits *d );
+/* bfsk_databits_decode(0, 0, 0, 0): minimodem.c:1351 */
+void mifsk_databits_reset( mifsk_databits *d );
+/* bfsk_databits_decode(out, out_size, bits, n_databits): returns the bytes
+ * produced (never more than out_size; the reference's 4096-byte buffer is the
+ * usual size) */
+unsigned mifsk_databits_decode( mifsk_databits *d, char *out, unsigned out_size,
+	unsigned long long bits, unsigned n_databits );
+
+#define MIFSK_TEXT_PRINT_FILTER	1u	/* -p, --print-filter (minimodem.c:1451-1460) */
+#define MIFSK_TEXT_QUIET	2u	/* -q, --quiet: no CARRIER / NOCARRIER lines  */
+
+/* Everything the reference writes for one stream: stdout (decoded text) and
+ * stderr ("### CARRIER ..." at each acquisition, "\n### NOCARRIER ..." with
+ * the episode statistics, minimodem.c:253-291,1336-1348) from the frame data
+ * bits in loop order (mifsk_demod_io.d_bits) and the episodes.  *out_len /
+ * *err_len receive the full lengths; at most the capacities are written.
+ * Returns 0, -ENOSPC when something was cut, -EINVAL. */
+int mifsk_stream_text( const mifsk_rx_config *cfg,
+	const uint64_t *bits, uint32_t nframes,
+	const mifsk_episode *episodes, uint32_t nepisodes, unsigned flags,
+	char *out, size_t out_cap, size_t *out_len,
+	char *err, size_t err_cap, size_t *err_len );
+
+/* ---- transmit side (test and benchmark input generator) ------------------ */
+
+/* simpleaudio_tone_init (simple-tone-generator.c:60-89); state is per call */
+int  mifsk_tx_tone_init( unsigned sin_table_len, float mag );
+/* fsk_transmit_stdin + simpleaudio_tone for one stream of data words
+ * (minimodem.c:81-250, simple-tone-generator.c:106-175): returns the stream's
+ * length in samples (also when out is NULL or too small), or -errno */
+long mifsk_tx_synthesize( const mifsk_rx_config *cfg, const uint8_t *words, size_t nwords,
+	unsigned sin_table_len, float amplitude, unsigned leading_silence, int as_s16,
+	float *out, size_t out_cap );
+
 #ifdef __cplusplus
 }
 #endif

@@ -320,3 +320,58 @@ def gather_bytes(local_bytes, local_nbytes, dst=0, group=None):
     for w in dist.batch_isend_irecv(reqs):
         w.wait()
     return None, None
+
+
+DECODERS = {"ascii8": 0, "baudot": 1, "binary": 2, "callerid": 3, "uic-ground": 4, "uic-train": 5}
+TEXT_PRINT_FILTER = 1
+TEXT_QUIET = 2
+
+
+class DataBits:
+    """One databits decoder with its state (include/mifsk.h, reference
+    src/databits.h:49-92): decode(bits, n_databits) -> bytes, reset()."""
+
+    def __init__(self, decoder):
+        self._lib = _lib.load()
+        self.h = C.c_void_p()
+        kind = DECODERS[decoder] if isinstance(decoder, str) else int(decoder)
+        rc = self._lib.mifsk_databits_create(C.byref(self.h), kind)
+        if rc != 0:
+            raise ValueError("mifsk_databits_create -> %d" % rc)
+        self._buf = C.create_string_buffer(4096)
+
+    def reset(self):
+        self._lib.mifsk_databits_reset(self.h)
+
+    def decode(self, bits, n_databits):
+        n = self._lib.mifsk_databits_decode(self.h, self._buf, 4096, int(bits), int(n_databits))
+        return self._buf.raw[:n]
+
+    def __del__(self):
+        try:
+            if self.h:
+                self._lib.mifsk_databits_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def stream_text(cfg, bits, episodes, print_filter=False, quiet=False):
+    """What minimodem writes for one stream: (stdout bytes, stderr str) from the
+    frame data bits (numpy uint64, loop order) and its episodes (EPISODE_DTYPE);
+    host post-pass mifsk_stream_text (reference src/minimodem.c:253-291,1336-1461)."""
+    lib = _lib.load()
+    bits = np.ascontiguousarray(bits, dtype=np.uint64)
+    episodes = np.ascontiguousarray(episodes, dtype=EPISODE_DTYPE)
+    flags = (TEXT_PRINT_FILTER if print_filter else 0) | (TEXT_QUIET if quiet else 0)
+    out_cap = 64 + 320 * max(1, bits.shape[0])
+    err_cap = 256 + 512 * max(1, episodes.shape[0])
+    out = C.create_string_buffer(out_cap)
+    err = C.create_string_buffer(err_cap)
+    nout, nerr = C.c_size_t(0), C.c_size_t(0)
+    rc = lib.mifsk_stream_text(C.byref(cfg), bits.ctypes.data, bits.shape[0],
+                               episodes.ctypes.data, episodes.shape[0], flags,
+                               out, out_cap, C.byref(nout), err, err_cap, C.byref(nerr))
+    if rc != 0:
+        raise RuntimeError("mifsk_stream_text -> %d" % rc)
+    return out.raw[:nout.value], err.raw[:nerr.value].decode("latin-1")

@@ -156,6 +156,8 @@ EXPORTS = [
     "mifsk_ctx_device_name", "mifsk_abi_version", "mifsk_find_frame_batch",
     "mifsk_demod_batch", "mifsk_demod_batch_host",
     "mifsk_tx_tone_init", "mifsk_tx_synthesize",
+    "mifsk_databits_create", "mifsk_databits_destroy", "mifsk_databits_reset",
+    "mifsk_databits_decode", "mifsk_stream_text",
 ]
 
 _lib = None
@@ -208,5 +210,16 @@ def load():
     lib.mifsk_tx_synthesize.argtypes = [C.POINTER(RxConfig), C.c_void_p, C.c_size_t,
                                         C.c_uint, C.c_float, C.c_uint, C.c_int,
                                         C.c_void_p, C.c_size_t]
+    lib.mifsk_databits_create.restype = C.c_int
+    lib.mifsk_databits_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    lib.mifsk_databits_destroy.argtypes = [C.c_void_p]
+    lib.mifsk_databits_reset.argtypes = [C.c_void_p]
+    lib.mifsk_databits_decode.restype = C.c_uint
+    lib.mifsk_databits_decode.argtypes = [C.c_void_p, C.c_char_p, C.c_uint, C.c_ulonglong, C.c_uint]
+    lib.mifsk_stream_text.restype = C.c_int
+    lib.mifsk_stream_text.argtypes = [C.POINTER(RxConfig), C.c_void_p, C.c_uint32, C.c_void_p,
+                                      C.c_uint32, C.c_uint, C.c_char_p, C.c_size_t,
+                                      C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t,
+                                      C.POINTER(C.c_size_t)]
     _lib = lib
     return lib

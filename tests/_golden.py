@@ -11,10 +11,10 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def names():
-    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "t[0-9]*.npz")))
 
 
-_INT_KEYS = {"sample_rate", "n_data_bits", "nstartbits"}
+_INT_KEYS = {"sample_rate", "n_data_bits", "nstartbits", "binary_output"}
 _FLOAT_KEYS = {"mark_f", "space_f", "band_width", "nstopbits"}
 
 
@@ -40,6 +40,17 @@ def load(name):
         "payload": z["payload"].tobytes(),
         "stdout": z["stdout"].tobytes(),
         "nocarrier": [str(s) for s in z["nocarrier"].tolist()],
+        "carrier": [str(s) for s in z["carrier"].tolist()],
+        "rx_args": [str(s) for s in z["rx_args"].tolist()],
         "trace": z["trace"],
         "cfg_kwargs": kw,
     }
+
+
+def raw_stdout(g):
+    """The bytes the ascii8 decoder produced, before `--print-filter` (the golden
+    stdout is what was printed; with the filter on, the unfiltered bytes are the
+    transmitted payload)."""
+    if "--print-filter" in g["rx_args"] or "-p" in g["rx_args"]:
+        return g["payload"]
+    return g["stdout"]

@@ -30,6 +30,16 @@ ASCII_PAYLOAD = (b"The quick brown fox jumps over the lazy dog 0123456789 "
                  b"!\"#$%&'()*+,-./:;<=>?@[\\]^_`{|}~ MI355X fsk\n")
 BAUDOT_PAYLOAD = b"THE QUICK BROWN FOX JUMPS OVER THE LAZY DOG 0123456789\n"
 
+
+
+def _ref_bytes(name):
+    path = os.path.join("/root/reference/tests", name)
+    if not os.path.exists(path):
+        return b""
+    with open(path, "rb") as f:
+        return f.read()
+
+
 # name, payload, tx args, rx args, oracle_config kwargs
 CASES = [
     ("t01_1200", ASCII_PAYLOAD, ["1200"], ["1200"], dict(baudmode="1200")),
@@ -60,6 +70,16 @@ CASES = [
      dict(baudmode="1200", n_data_bits=7)),
     ("t80_same", ASCII_PAYLOAD, ["same"], ["same"], dict(baudmode="same")),
     ("t81_tdd", BAUDOT_PAYLOAD[:24], ["tdd"], ["tdd"], dict(baudmode="tdd")),
+    # tests/70-callerid-mdmf.test, 71-callerid-sdmf.test: the reference's own message bytes
+    ("t70_callerid_mdmf", _ref_bytes("testdata-callerid-mdmf.bytes"), ["1200", "--ascii"],
+     ["callerid"], dict(baudmode="callerid")),
+    ("t71_callerid_sdmf", _ref_bytes("testdata-callerid-sdmf.bytes"), ["1200", "--ascii"],
+     ["callerid"], dict(baudmode="callerid")),
+    # output modes of the databits post-pass
+    ("t90_binary_output", ASCII_PAYLOAD[:40], ["1200"], ["1200", "--binary-output"],
+     dict(baudmode="1200", binary_output=1)),
+    ("t91_print_filter", b"tab\there \x01\x02 bell\x07 del\x7f high\xe9\xff nl\n cr\r end",
+     ["1200"], ["1200", "--print-filter"], dict(baudmode="1200")),
 ]
 
 

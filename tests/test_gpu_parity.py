@@ -80,9 +80,19 @@ def test_demod_matches_oracle_and_reference_on_goldens(gpu, name):
     assert_stream_equal(res, 0, ref, name)
     # and, transitively, the reference program's own output for this input
     if cfg.decoder == 0:
-        assert res["bytes"][0, :int(res["nbytes"][0])].tobytes() == g["stdout"]
+        assert res["bytes"][0, :int(res["nbytes"][0])].tobytes() == G.raw_stdout(g)
     lines = [O.format_nocarrier(ocfg, e) for e in res["episodes"][0, :int(res["nepisodes"][0])]]
     assert lines == g["nocarrier"]
+    # device frame bits + episodes -> host post-pass (mifsk_stream_text) == everything the
+    # reference printed: stdout through its databits decoder (ascii, baudot, caller-ID,
+    # binary, print filter) and the CARRIER / NOCARRIER lines on stderr
+    out, err = M.stream_text(cfg, res["bits"][0, :int(res["nframes"][0])],
+                             res["episodes"][0, :int(res["nepisodes"][0])],
+                             print_filter="--print-filter" in g["rx_args"])
+    assert out == g["stdout"]
+    elines = [l for l in err.splitlines() if l]
+    assert [l for l in elines if l.startswith("### CARRIER")] == g["carrier"]
+    assert [l for l in elines if l.startswith("### NOCARRIER")] == g["nocarrier"]
 
 
 @pytest.mark.parametrize("name", G.names())

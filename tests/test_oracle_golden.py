@@ -18,7 +18,7 @@ def test_rx_stream_matches_reference_output(name, ring):
     cfg = O.oracle_config(**g["cfg_kwargs"])
     r = O.oracle_rx_stream(cfg, g["samples"], ring_mode=ring)
     if cfg.decoder == 0:     # ascii8: bytes are directly comparable
-        assert r["bytes"] == g["stdout"]
+        assert r["bytes"] == G.raw_stdout(g)
     lines = [O.format_nocarrier(cfg, e) for e in r["episodes"]]
     assert lines == g["nocarrier"]
 
