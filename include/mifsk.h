@@ -282,6 +282,38 @@ int mifsk_stream_text( const mifsk_rx_config *cfg,
 	char *out, size_t out_cap, size_t *out_len,
 	char *err, size_t err_cap, size_t *err_len );
 
+/* ---- input side: the step before the path ------------------- */
+
+/* RIFF/WAVE header of a `--rx --file` input: PCM16 or IEEE float32, mono
+ * (what the reference reads through libsndfile in its tests;
+ * simpleaudio-sndfile.c:113-160).  -EINVAL: not a WAV file; -ENOTSUP: a
+ * format or channel count the receive path does not take. */
+typedef struct mifsk_wav_info {
+    unsigned	sample_rate;
+    unsigned	channels;
+    unsigned	bits_per_sample;
+    int		is_float;
+    size_t	data_offset;	/* bytes from the start of the file */
+    size_t	nframes;
+} mifsk_wav_info;
+
+int mifsk_wav_parse( const void *file, size_t len, mifsk_wav_info *info );
+
+/* sf_readf_float() on 16-bit input, for a whole batch on the device:
+ * d_samples[s][i] = d_pcm[s][i] / 32768 (+ the --Xrxnoise term) for
+ * i < nsamples[s], 0.0 up to stream_stride.  `rxnoise` is the option's factor
+ * (0 = off): the reference adds (rand()/RAND_MAX - 0.5f) * 2 * factor with an
+ * INTEGER division, i.e. the constant -factor (simpleaudio-sndfile.c:64-69;
+ * tests/40-noise.test sweeps it as a DC offset).  Strides in elements;
+ * fastest when pcm_stride % 8 == 0, stream_stride % 4 == 0 and both bases are
+ * 16-byte aligned.  Asynchronous on `stream`. */
+int mifsk_ingest_s16( mifsk_ctx *ctx, const int16_t *d_pcm, size_t pcm_stride,
+	float *d_samples, size_t stream_stride, const uint32_t *d_nsamples, uint32_t nsamples,
+	int nstreams, float rxnoise, void *stream );
+/* the --Xrxnoise term alone, in place, for input that is already float */
+int mifsk_ingest_rxnoise_f32( mifsk_ctx *ctx, float *d_samples, size_t stream_stride,
+	const uint32_t *d_nsamples, uint32_t nsamples, int nstreams, float rxnoise, void *stream );
+
 /* ---- transmit side (test and benchmark input generator) ------------------ */
 
 /* simpleaudio_tone_init (simple-tone-generator.c:60-89); state is per call */

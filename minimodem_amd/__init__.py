@@ -375,3 +375,46 @@ def stream_text(cfg, bits, episodes, print_filter=False, quiet=False):
     if rc != 0:
         raise RuntimeError("mifsk_stream_text -> %d" % rc)
     return out.raw[:nout.value], err.raw[:nerr.value].decode("latin-1")
+
+
+def wav_parse(data):
+    """RIFF/WAVE header of a `--rx --file` input (mifsk_wav_parse): dict with
+    sample_rate, channels, bits_per_sample, is_float, data_offset, nframes."""
+    info = _lib.WavInfo()
+    rc = _lib.load().mifsk_wav_parse(data, len(data), C.byref(info))
+    if rc != 0:
+        raise ValueError("mifsk_wav_parse -> %d" % rc)
+    return {k: getattr(info, k) for k, _ in info._fields_}
+
+
+def ingest_s16(ctx, pcm, nsamples=None, rxnoise=0.0, stride=None, stream=None):
+    """libsndfile's S16 -> float conversion (+ the --Xrxnoise term) on the device:
+    pcm is a torch.int16 CUDA tensor [nstreams, width]; returns float32
+    [nstreams, stride] (stride defaults to width rounded up to a multiple of 4)."""
+    torch = _torch()
+    assert pcm.is_cuda and pcm.dtype == torch.int16 and pcm.dim() == 2 and pcm.stride(1) == 1
+    nstreams, width = pcm.shape
+    if stride is None:
+        stride = (width + 3) & ~3
+    out = torch.empty((nstreams, stride), dtype=torch.float32, device=pcm.device)
+    rc = _lib.load().mifsk_ingest_s16(
+        ctx.handle, C.c_void_p(pcm.data_ptr()), pcm.stride(0) if nstreams > 1 else width,
+        C.c_void_p(out.data_ptr()), stride,
+        C.c_void_p(nsamples.data_ptr()) if nsamples is not None else None, int(width), nstreams,
+        C.c_float(rxnoise), _stream_ptr(torch, stream))
+    if rc != 0:
+        raise RuntimeError("mifsk_ingest_s16 -> %d" % rc)
+    return out
+
+
+def ingest_rxnoise(ctx, samples, rxnoise, nsamples=None, stream=None):
+    """The --Xrxnoise term applied in place to float32 CUDA samples [nstreams, stride]."""
+    torch = _torch()
+    assert samples.is_cuda and samples.dtype == torch.float32 and samples.dim() == 2
+    rc = _lib.load().mifsk_ingest_rxnoise_f32(
+        ctx.handle, C.c_void_p(samples.data_ptr()), samples.stride(0),
+        C.c_void_p(nsamples.data_ptr()) if nsamples is not None else None, int(samples.shape[1]),
+        samples.shape[0], C.c_float(rxnoise), _stream_ptr(torch, stream))
+    if rc != 0:
+        raise RuntimeError("mifsk_ingest_rxnoise_f32 -> %d" % rc)
+    return samples

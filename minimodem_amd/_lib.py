@@ -144,6 +144,11 @@ class FskPlan(C.Structure):
     ]
 
 
+class WavInfo(C.Structure):
+    _fields_ = [("sample_rate", C.c_uint), ("channels", C.c_uint), ("bits_per_sample", C.c_uint),
+                ("is_float", C.c_int), ("data_offset", C.c_size_t), ("nframes", C.c_size_t)]
+
+
 assert C.sizeof(FskPlan) == 64 and FskPlan.fftplan.offset == 40
 assert C.sizeof(Search) == 32 and C.sizeof(SearchResult) == 24
 
@@ -158,6 +163,7 @@ EXPORTS = [
     "mifsk_tx_tone_init", "mifsk_tx_synthesize",
     "mifsk_databits_create", "mifsk_databits_destroy", "mifsk_databits_reset",
     "mifsk_databits_decode", "mifsk_stream_text",
+    "mifsk_wav_parse", "mifsk_ingest_s16", "mifsk_ingest_rxnoise_f32",
 ]
 
 _lib = None
@@ -221,5 +227,13 @@ def load():
                                       C.c_uint32, C.c_uint, C.c_char_p, C.c_size_t,
                                       C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t,
                                       C.POINTER(C.c_size_t)]
+    lib.mifsk_wav_parse.restype = C.c_int
+    lib.mifsk_wav_parse.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(WavInfo)]
+    lib.mifsk_ingest_s16.restype = C.c_int
+    lib.mifsk_ingest_s16.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                     C.c_void_p, C.c_uint32, C.c_int, C.c_float, C.c_void_p]
+    lib.mifsk_ingest_rxnoise_f32.restype = C.c_int
+    lib.mifsk_ingest_rxnoise_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                             C.c_uint32, C.c_int, C.c_float, C.c_void_p]
     _lib = lib
     return lib

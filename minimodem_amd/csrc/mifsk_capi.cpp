@@ -132,6 +132,8 @@ struct mifsk_ctx {
 	fprintf(stderr, "mifsk: %s failed: %s\n", #call, hipGetErrorString(e_)); \
 	return -EIO; } } while (0)
 
+int mifsk::ctx_device( const mifsk_ctx *ctx ) { return ctx->device; }
+
 extern "C" int mifsk_abi_version( void ) { return MIFSK_ABI_VERSION; }
 
 extern "C" int mifsk_ctx_create( mifsk_ctx **out, int device )

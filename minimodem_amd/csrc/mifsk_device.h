@@ -60,4 +60,7 @@ int launch_detect_carrier( const float *d_samples, unsigned nsamples,
 	const double *d_cs /* [fftsize][2] */, unsigned fftsize, unsigned nbands,
 	float *d_mags /* [nbands] */, void *stream );
 
+// the HIP device a context is bound to (mifsk_capi.cpp)
+int ctx_device( const mifsk_ctx *ctx );
+
 } // namespace mifsk

@@ -33,8 +33,15 @@ def load(name):
         x = s.astype(np.float32) / np.float32(32768.0)   # libsndfile S16 -> float
     else:
         x = s.astype(np.float32)
+    rx_args = [str(a) for a in z["rx_args"].tolist()]
+    rxnoise = float(rx_args[rx_args.index("--Xrxnoise") + 1]) if "--Xrxnoise" in rx_args else 0.0
+    if rxnoise:
+        # simpleaudio-sndfile.c:64-69 with rand()/RAND_MAX == 0 (integer division)
+        x = x + (np.float32(0) - np.float32(0.5)) * (np.float32(rxnoise) * np.float32(2))
     return {
         "name": name,
+        "stored": s,            # the samples in their on-disk encoding (int16 or float32)
+        "rxnoise": rxnoise,
         "samples": x,
         "sample_rate": int(z["sample_rate"]),
         "payload": z["payload"].tobytes(),

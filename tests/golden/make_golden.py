@@ -78,6 +78,11 @@ CASES = [
     # output modes of the databits post-pass
     ("t90_binary_output", ASCII_PAYLOAD[:40], ["1200"], ["1200", "--binary-output"],
      dict(baudmode="1200", binary_output=1)),
+    # tests/40-noise.test: --Xrxnoise adds the constant -factor (integer division of rand())
+    ("t40_rxnoise_0p10", ASCII_PAYLOAD[:40], ["--volume", "0.5", "1200"],
+     ["--Xrxnoise", "0.10", "1200"], dict(baudmode="1200")),
+    ("t40_rxnoise_0p50_float", ASCII_PAYLOAD[:40], ["--volume", "0.5", "1200", "--float-samples"],
+     ["--Xrxnoise", "0.50", "1200"], dict(baudmode="1200")),
     ("t91_print_filter", b"tab\there \x01\x02 bell\x07 del\x7f high\xe9\xff nl\n cr\r end",
      ["1200"], ["1200", "--print-filter"], dict(baudmode="1200")),
 ]
@@ -139,7 +144,11 @@ def main():
             assert np.array_equal(stored.astype(np.float32) / np.float32(32768.0), x)
         cfg = O.oracle_config(**kw)
         assert cfg.sample_rate == sr
-        trace = find_frame_trace(cfg, x)
+        x_rx = x
+        if "--Xrxnoise" in rx:      # what the receive loop sees (simpleaudio-sndfile.c:64-69)
+            f = np.float32(float(rx[rx.index("--Xrxnoise") + 1]))
+            x_rx = x + (np.float32(0) - np.float32(0.5)) * (f * np.float32(2))
+        trace = find_frame_trace(cfg, x_rx)
         stats = [l for l in err.splitlines() if l.startswith("### NOCARRIER")]
         carriers = [l for l in err.splitlines() if l.startswith("### CARRIER")]
         path = os.path.join(HERE, name + ".npz")

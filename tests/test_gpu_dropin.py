@@ -24,13 +24,11 @@ DROPIN = os.path.join(O.REF_DIR, "minimodem_mifsk")
 
 
 def _write_wav(path, g):
-    x = g["samples"]
-    z = np.load(os.path.join(G.GOLDEN_DIR, g["name"] + ".npz"), allow_pickle=False)
-    raw = z["samples"]
+    raw = g["stored"]           # the file as the reference wrote it (before any --Xrxnoise)
     if raw.dtype == np.int16:
         data, tag, bits = raw.astype("<i2").tobytes(), 1, 16
     else:
-        data, tag, bits = x.astype("<f4").tobytes(), 3, 32
+        data, tag, bits = raw.astype("<f4").tobytes(), 3, 32
     sr = g["sample_rate"]
     with open(path, "wb") as f:
         f.write(b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVEfmt ")
