@@ -356,11 +356,18 @@ class DataBits:
             pass
 
 
-def stream_text(cfg, bits, episodes, print_filter=False, quiet=False):
+def stream_text(cfg, bits, episodes, print_filter=False, quiet=False, b_mark=None):
     """What minimodem writes for one stream: (stdout bytes, stderr str) from the
     frame data bits (numpy uint64, loop order) and its episodes (EPISODE_DTYPE);
-    host post-pass mifsk_stream_text (reference src/minimodem.c:253-291,1336-1461)."""
+    host post-pass mifsk_stream_text (reference src/minimodem.c:253-291,1336-1461).
+    b_mark: the stream's autodetected mark band (--auto-carrier), which the
+    "### CARRIER ... @ f Hz" line is printed from."""
     lib = _lib.load()
+    if b_mark is not None and int(b_mark) >= 0:
+        c2 = RxConfig()
+        C.memmove(C.byref(c2), C.byref(cfg), C.sizeof(RxConfig))
+        c2.b_mark = int(b_mark)
+        cfg = c2
     bits = np.ascontiguousarray(bits, dtype=np.uint64)
     episodes = np.ascontiguousarray(episodes, dtype=EPISODE_DTYPE)
     flags = (TEXT_PRINT_FILTER if print_filter else 0) | (TEXT_QUIET if quiet else 0)

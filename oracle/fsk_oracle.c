@@ -278,11 +278,17 @@ ofsk_detect_carrier( ofsk_plan *p, const float *samples, unsigned int nsamples,
     if ( nsamples > (unsigned int)p->fftsize )	/* assert in the reference (fsk.c:547) */
 	return -1;
     const unsigned int N = p->fftsize;
-    double *cs = malloc(sizeof(double) * 2 * N);
-    for ( unsigned int k = 0; k < N; k++ ) {
-	double ang = 2.0 * M_PI * (double)k / (double)N;
-	cs[2 * k] = cos(ang);
-	cs[2 * k + 1] = -sin(ang);
+    static double *cs;			/* table of the last fftsize (test infrastructure: one thread) */
+    static unsigned int cs_n;
+    if ( cs_n != N ) {
+	free(cs);
+	cs = malloc(sizeof(double) * 2 * N);
+	for ( unsigned int k = 0; k < N; k++ ) {
+	    double ang = 2.0 * M_PI * (double)k / (double)N;
+	    cs[2 * k] = cos(ang);
+	    cs[2 * k + 1] = -sin(ang);
+	}
+	cs_n = N;
     }
     float magscalar = 1.0f / ((float)nsamples / 2.0f);		/* fsk.c:553 */
     float max_mag = 0.0f;
@@ -303,7 +309,6 @@ ofsk_detect_carrier( ofsk_plan *p, const float *samples, unsigned int nsamples,
 	    max_band = (int)b;
 	}
     }
-    free(cs);
     return max_band;
 }
 
@@ -600,12 +605,80 @@ push_episode( ofsk_rx_result *res, size_t first_frame, unsigned int nframes,
     res->nepisodes++;
 }
 
+/* the space band that goes with an autodetected mark band (minimodem.c:1203-1215);
+ * returns 0 when the pair is rejected */
+static int
+auto_space_band( const mifsk_rx_config *cfg, const ofsk_plan *p, int carrier_band, int *b_shift_out )
+{
+    int b_shift = - (float)(cfg->autodetect_shift + p->band_width / 2.0f) / p->band_width;
+    if ( cfg->inverted_freqs )
+	b_shift *= -1;
+    int b_space = carrier_band + b_shift;
+    *b_shift_out = b_shift;
+    return !( b_space < 1 || b_space >= (int)p->nbands );
+}
+
+/*
+ * --auto-carrier under flat addressing.  Until a carrier is found the loop does
+ * nothing but shift and refill its buffer and scan it (minimodem.c:1144-1200),
+ * so which windows get scanned is fixed by the buffer arithmetic alone: this
+ * replays that arithmetic on (pos = absolute index of samplebuf[0], nvalid)
+ * without a buffer.  Returns the band (and *pos_out = where samplebuf[0] sits
+ * when it is found: the main search starts there), or -1.
+ */
+static int
+auto_carrier_scan_flat( const mifsk_rx_config *cfg, ofsk_plan *p, const float *x, size_t nsamples,
+	size_t *pos_out, int *b_shift_out, unsigned long long *nwin )
+{
+    const size_t bufsize = cfg->samplebuf_size;
+    float nps = cfg->nsamples_per_bit;				/* :1182-1184 */
+    if ( nps > p->fftsize )
+	nps = p->fftsize;
+    size_t pos = 0, nvalid = 0;
+    unsigned int advance = 0;
+    for (;;) {
+	if ( advance == bufsize ) {				/* :1146-1149 */
+	    nvalid = 0;
+	    pos += advance;
+	    advance = 0;
+	}
+	if ( advance ) {					/* :1150-1156 */
+	    if ( advance > nvalid )
+		return -1;
+	    pos += advance;
+	    nvalid -= advance;
+	}
+	if ( nvalid < bufsize / 2 ) {				/* :1158-1174 */
+	    size_t got = pos + nvalid;
+	    size_t r = nsamples - got < bufsize / 2 ? nsamples - got : bufsize / 2;
+	    nvalid += r;
+	}
+	if ( nvalid == 0 )					/* :1176 */
+	    return -1;
+	unsigned int i;
+	int band = -1;
+	for ( i = 0; i + nps <= nvalid; i += nps ) {		/* :1185-1192 */
+	    band = ofsk_detect_carrier(p, x + pos + i, nps, cfg->auto_carrier_threshold);
+	    (*nwin)++;
+	    if ( band >= 0 )
+		break;
+	}
+	advance = i + nps;					/* :1193-1195 */
+	if ( advance > nvalid )
+	    advance = nvalid;
+	if ( band < 0 )
+	    continue;
+	if ( !auto_space_band(cfg, p, band, b_shift_out) )	/* :1209-1213 */
+	    continue;
+	*pos_out = pos;
+	return band;
+    }
+}
+
 int
 ofsk_rx_stream( const mifsk_rx_config *cfg, const float *samples, size_t nsamples,
 	int ring_mode, ofsk_rx_result *res )
 {
-    if ( cfg->auto_carrier_threshold > 0.0f )
-	return -ENOSYS;
 
     ofsk_plan *p = ofsk_plan_new((float)cfg->sample_rate, cfg->mark_f, cfg->space_f,
 				 cfg->band_width);
@@ -638,6 +711,24 @@ ofsk_rx_stream( const mifsk_rx_config *cfg, const float *samples, size_t nsample
 
     res->nframes = res->nepisodes = res->nbytes = 0;
     res->n_iterations = res->n_find_frame = res->n_positions = 0;
+    res->carrier_band = -1;
+    res->carrier_b_space = 0;
+    res->n_scan_windows = 0;
+    const int autodetect = cfg->auto_carrier_threshold > 0.0f;
+    int carrier_band = -1;		/* `static` in the reference: found once per run */
+    if ( autodetect && !ring_mode ) {
+	int b_shift = 0;
+	carrier_band = auto_carrier_scan_flat(cfg, p, buf, nsamples, &base, &b_shift,
+					      &res->n_scan_windows);
+	if ( carrier_band < 0 ) {
+	    free(buf);
+	    ofsk_plan_destroy(p);
+	    return 0;			/* no carrier anywhere: nothing is decoded */
+	}
+	ofsk_set_tones_by_bandshift(p, (unsigned int)carrier_band, b_shift);
+	res->carrier_band = carrier_band;
+	res->carrier_b_space = p->b_space;
+    }
 
     int carrier = 0;
     float confidence_total = 0, amplitude_total = 0;
@@ -684,6 +775,31 @@ ofsk_rx_stream( const mifsk_rx_config *cfg, const float *samples, size_t nsample
 	}
 	if ( nvalid == 0 )
 	    break;
+	if ( autodetect && carrier_band < 0 ) {			/* ring mode only; :1179-1220 */
+	    unsigned int i;
+	    float nps = spb;
+	    if ( nps > p->fftsize )
+		nps = p->fftsize;
+	    for ( i = 0; i + nps <= nvalid; i += nps ) {
+		carrier_band = ofsk_detect_carrier(p, win + i, nps, cfg->auto_carrier_threshold);
+		res->n_scan_windows++;
+		if ( carrier_band >= 0 )
+		    break;
+	    }
+	    advance = i + nps;
+	    if ( advance > nvalid )
+		advance = nvalid;
+	    if ( carrier_band < 0 )
+		continue;
+	    int b_shift;
+	    if ( !auto_space_band(cfg, p, carrier_band, &b_shift) ) {
+		carrier_band = -1;
+		continue;
+	    }
+	    ofsk_set_tones_by_bandshift(p, (unsigned int)carrier_band, b_shift);
+	    res->carrier_band = carrier_band;
+	    res->carrier_b_space = p->b_space;
+	}
 	if ( nvalid < expect_nsamples )				/* :1229 */
 	    break;
 	res->n_iterations++;

@@ -107,6 +107,11 @@ typedef struct ofsk_rx_result {
     mifsk_episode	*episodes;	size_t episodes_cap;	size_t nepisodes;
     uint8_t		*bytes;		size_t bytes_cap;	size_t nbytes;
     /* work counters */
+    /* --auto-carrier (minimodem.c:1179-1220): the band the mark tone was found in
+     * (-1: never / not asked for), the space band derived from it, windows scanned */
+    int			carrier_band;
+    unsigned int	carrier_b_space;
+    unsigned long long	n_scan_windows;
     unsigned long long	n_iterations;
     unsigned long long	n_find_frame;
     unsigned long long	n_positions;

@@ -14,8 +14,8 @@ def names():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "t[0-9]*.npz")))
 
 
-_INT_KEYS = {"sample_rate", "n_data_bits", "nstartbits", "binary_output"}
-_FLOAT_KEYS = {"mark_f", "space_f", "band_width", "nstopbits"}
+_INT_KEYS = {"sample_rate", "n_data_bits", "nstartbits", "binary_output", "inverted_freqs"}
+_FLOAT_KEYS = {"mark_f", "space_f", "band_width", "nstopbits", "auto_carrier_threshold"}
 
 
 def load(name):

@@ -139,6 +139,8 @@ class RxResult(C.Structure):
         ("frames", C.c_void_p), ("frames_cap", C.c_size_t), ("nframes", C.c_size_t),
         ("episodes", C.c_void_p), ("episodes_cap", C.c_size_t), ("nepisodes", C.c_size_t),
         ("bytes", C.c_void_p), ("bytes_cap", C.c_size_t), ("nbytes", C.c_size_t),
+        ("carrier_band", C.c_int), ("carrier_b_space", C.c_uint),
+        ("n_scan_windows", C.c_ulonglong),
         ("n_iterations", C.c_ulonglong),
         ("n_find_frame", C.c_ulonglong),
         ("n_positions", C.c_ulonglong),
@@ -309,6 +311,9 @@ def oracle_rx_stream(cfg, samples, ring_mode=False):
         "frames": frames[: res.nframes].copy(),
         "episodes": episodes[: res.nepisodes].copy(),
         "bytes": out_bytes[: res.nbytes].tobytes(),
+        "carrier_band": int(res.carrier_band),
+        "carrier_b_space": int(res.carrier_b_space),
+        "n_scan_windows": int(res.n_scan_windows),
         "n_iterations": int(res.n_iterations),
         "n_find_frame": int(res.n_find_frame),
         "n_positions": int(res.n_positions),
@@ -349,6 +354,20 @@ def read_wav(path):
             return sr, x
         pos += 8 + ln + (ln & 1)
     raise ValueError("no data chunk")
+
+
+def write_wav(path, x, sample_rate, s16):
+    """mono WAV: PCM16 from an int16 array, or IEEE float32"""
+    import struct
+    if s16:
+        data, tag, bits = np.asarray(x, "<i2").tobytes(), 1, 16
+    else:
+        data, tag, bits = np.asarray(x, "<f4").tobytes(), 3, 32
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVEfmt ")
+        f.write(struct.pack("<IHHIIHH", 16, tag, 1, sample_rate, sample_rate * bits // 8,
+                            bits // 8, bits))
+        f.write(b"data" + struct.pack("<I", len(data)) + data)
 
 
 def ref_tx(payload, tx_args, path):

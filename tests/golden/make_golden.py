@@ -78,6 +78,19 @@ CASES = [
     # output modes of the databits post-pass
     ("t90_binary_output", ASCII_PAYLOAD[:40], ["1200"], ["1200", "--binary-output"],
      dict(baudmode="1200", binary_output=1)),
+    # --auto-carrier (minimodem.c:1179-1220, fsk.c:543-598): standard tones, moved tones behind
+    # leading silence that is not a whole number of scan windows, inverted tones, long windows
+    ("t50_auto_300", ASCII_PAYLOAD[:32], ["300"], ["--auto-carrier", "300"],
+     dict(baudmode="300", auto_carrier_threshold=0.001)),
+    ("t50_auto_300_moved_lead", ASCII_PAYLOAD[:32], ["300", "-M", "1570", "-S", "1370"],
+     ["--auto-carrier", "300"], dict(baudmode="300", auto_carrier_threshold=0.001), dict(lead=10007)),
+    ("t50_auto_1200_lead", ASCII_PAYLOAD[:40], ["1200"], ["--auto-carrier", "1200"],
+     dict(baudmode="1200", auto_carrier_threshold=0.001), dict(lead=30001)),
+    ("t50_auto_300_inverted", ASCII_PAYLOAD[:32], ["300", "-M", "1070", "-S", "1270"],
+     ["--auto-carrier", "-i", "300"],
+     dict(baudmode="300", auto_carrier_threshold=0.001, inverted_freqs=1), dict(lead=333)),
+    ("t50_auto_rtty_lead", BAUDOT_PAYLOAD[:12], ["rtty"], ["--auto-carrier", "rtty"],
+     dict(baudmode="rtty", auto_carrier_threshold=0.001), dict(lead=5000)),
     # tests/40-noise.test: --Xrxnoise adds the constant -factor (integer division of rand())
     ("t40_rxnoise_0p10", ASCII_PAYLOAD[:40], ["--volume", "0.5", "1200"],
      ["--Xrxnoise", "0.10", "1200"], dict(baudmode="1200")),
@@ -125,10 +138,22 @@ def find_frame_trace(cfg, x, max_calls=24):
 
 def main():
     assert O.have_ref(), "oracle/_ref missing: run `make -C oracle` where /root/reference exists"
-    for name, payload, tx, rx, kw in CASES:
+    for case in CASES:
+        name, payload, tx, rx, kw = case[:5]
+        extra = case[5] if len(case) > 5 else {}
         wav = O.tmp_wav()
         try:
             O.ref_tx(payload, tx, wav)
+            if extra.get("lead"):       # leading silence: rewrite the reference's file
+                with open(wav, "rb") as f:
+                    raw0 = f.read()
+                sr0, x0 = O.read_wav(wav)
+                if "--float-samples" in tx:
+                    body = np.concatenate([np.zeros(extra["lead"], "<f4"), x0.astype("<f4")])
+                else:
+                    body = np.concatenate([np.zeros(extra["lead"], "<i2"),
+                                           np.frombuffer(raw0[44:], dtype="<i2")])
+                O.write_wav(wav, body, sr0, "--float-samples" not in tx)
             out, err = O.ref_rx(wav, rx)
             with open(wav, "rb") as f:
                 raw = f.read()

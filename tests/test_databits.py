@@ -58,7 +58,8 @@ def test_stream_text_matches_reference_stdout_and_stderr(name):
     g = G.load(name)
     cfg = M.rx_config(**g["cfg_kwargs"])
     r = O.oracle_rx_stream(O.oracle_config(**g["cfg_kwargs"]), g["samples"])
-    out, err = M.stream_text(cfg, r["frames"]["bits"], r["episodes"], print_filter=_print_filter(g))
+    out, err = M.stream_text(cfg, r["frames"]["bits"], r["episodes"], print_filter=_print_filter(g),
+                             b_mark=r["carrier_band"])
     assert out == g["stdout"]
     lines = [l for l in err.splitlines() if l]
     assert [l for l in lines if l.startswith("### CARRIER")] == g["carrier"]
@@ -66,7 +67,7 @@ def test_stream_text_matches_reference_stdout_and_stderr(name):
     # each NOCARRIER line is preceded by an empty line, as the reference prints it
     assert err.count("\n### NOCARRIER") == len(g["nocarrier"])
     q_out, q_err = M.stream_text(cfg, r["frames"]["bits"], r["episodes"], quiet=True,
-                                 print_filter=_print_filter(g))
+                                 print_filter=_print_filter(g), b_mark=r["carrier_band"])
     assert q_out == out and q_err == ""
 
 
