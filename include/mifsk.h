@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define MIFSK_MAX_FRAME_BITS	64	/* fsk.c:185-187,463 */
-#define MIFSK_ABI_VERSION	1
+#define MIFSK_ABI_VERSION	2
 
 /* which databits decoder main() would have selected (minimodem.c:549-553,
  * 675,820,856,866,892).  Decoding frame bits to text is O(1)/frame host work
@@ -70,8 +70,9 @@ typedef struct mifsk_modem_args {
     int		binary_output;	/* --binary-output                         */
     int		binary_raw_nbits;	/* --binary-raw N                  */
     int		rx_one;		/* --rx-one                                */
-    float	auto_carrier_threshold;	/* -a -> 0.001; not supported by the
-					   batch path yet (-ENOSYS)        */
+    float	auto_carrier_threshold;	/* -a -> 0.001, -A x -> x: find the mark
+					   tone per stream before the first
+					   search (minimodem.c:1179-1220)  */
 } mifsk_modem_args;
 
 /* Everything main() derives before entering the receive loop, computed on the
@@ -222,6 +223,10 @@ typedef struct mifsk_demod_io {
     uint32_t		*d_status;	/* [nstreams] MIFSK_STREAM_* or NULL */
     uint64_t		*d_counters;	/* [nstreams][MIFSK_NCOUNTERS] work
 					   counters (MIFSK_CNT_*) or NULL    */
+    int32_t		*d_carrier_band;/* [nstreams] or NULL; --auto-carrier
+					   only: the band the mark tone was
+					   detected in, -1 = no carrier found
+					   (the stream then yields nothing)  */
 } mifsk_demod_io;
 
 /* per-stream work counters (diagnostics; cycle counts are s_memtime ticks) */

@@ -147,6 +147,8 @@ def demod_batch(ctx, cfg, samples, nsamples=None, want=("bytes", "episodes"),
                                         dtype=torch.uint8, device=dev)
         if "counters" in want:
             out["counters"] = torch.zeros((nstreams, NCOUNTERS), dtype=torch.int64, device=dev)
+        if "carrier_band" in want or cfg.auto_carrier_threshold > 0:
+            out["carrier_band"] = torch.full((nstreams,), -1, dtype=torch.int32, device=dev)
         if "episodes" in want:
             out["episodes"] = torch.zeros((nstreams, episodes_cap, EPISODE_DTYPE.itemsize),
                                           dtype=torch.uint8, device=dev)
@@ -173,6 +175,7 @@ def demod_batch(ctx, cfg, samples, nsamples=None, want=("bytes", "episodes"),
     io.episodes_cap = episodes_cap
     io.d_status = ptr("status")
     io.d_counters = ptr("counters")
+    io.d_carrier_band = ptr("carrier_band")
     rc = lib.mifsk_demod_batch(ctx.handle, C.byref(cfg), C.byref(io), _stream_ptr(torch, stream))
     if rc != 0:
         raise RuntimeError("mifsk_demod_batch failed: %d" % rc)

@@ -131,6 +131,7 @@ class DemodIO(C.Structure):
         ("episodes_cap", C.c_size_t),
         ("d_status", C.c_void_p),
         ("d_counters", C.c_void_p),
+        ("d_carrier_band", C.c_void_p),
     ]
 
 

@@ -126,6 +126,11 @@ struct mifsk_ctx {
     // spectrum table for fsk_detect_carrier
     unsigned		cs_fftsize;
     double		*d_cs;
+    // --auto-carrier scratch (grow-only): per-stream band, start cursor, table pointer
+    size_t		auto_cap;
+    int32_t		*d_auto_band;
+    uint32_t		*d_auto_start;
+    const double	**d_auto_tw;
 };
 
 #define HIP_OK(call)	do { hipError_t e_ = (call); if ( e_ != hipSuccess ) { \
@@ -167,6 +172,10 @@ extern "C" int mifsk_ctx_create( mifsk_ctx **out, int device )
     std::snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
     ctx->cs_fftsize = 0;
     ctx->d_cs = nullptr;
+    ctx->auto_cap = 0;
+    ctx->d_auto_band = nullptr;
+    ctx->d_auto_start = nullptr;
+    ctx->d_auto_tw = nullptr;
     *out = ctx;
     return 0;
 }
@@ -181,6 +190,9 @@ extern "C" void mifsk_ctx_destroy( mifsk_ctx *ctx )
 	(void)hipFree(e.dev);
     if ( ctx->d_cs )
 	(void)hipFree(ctx->d_cs);
+    if ( ctx->d_auto_band ) (void)hipFree(ctx->d_auto_band);
+    if ( ctx->d_auto_start ) (void)hipFree(ctx->d_auto_start);
+    if ( ctx->d_auto_tw ) (void)hipFree(ctx->d_auto_tw);
     delete ctx;
 }
 
@@ -244,6 +256,28 @@ static int get_devcfg( mifsk_ctx *ctx, const DevCfg &d, const DevCfg **d_out )
     return 0;
 }
 
+// cos / -sin of 2 pi k / N for k < N (the spectrum table of fsk_detect_carrier)
+static int get_cs( mifsk_ctx *ctx, unsigned N, const double **d_out )
+{
+    if ( ctx->cs_fftsize != N ) {
+	std::vector<double> h(2 * (size_t)N);
+	for ( unsigned k = 0; k < N; k++ ) {
+	    const double ang = 2.0 * M_PI * (double)k / (double)N;
+	    h[2 * (size_t)k] = std::cos(ang);
+	    h[2 * (size_t)k + 1] = -std::sin(ang);
+	}
+	if ( ctx->d_cs ) (void)hipFree(ctx->d_cs);
+	ctx->d_cs = nullptr;
+	ctx->cs_fftsize = 0;
+	if ( hipMalloc(&ctx->d_cs, h.size() * sizeof(double)) != hipSuccess
+		|| hipMemcpy(ctx->d_cs, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess )
+	    return -ENOMEM;
+	ctx->cs_fftsize = N;
+    }
+    *d_out = ctx->d_cs;
+    return 0;
+}
+
 static int check_cfg( const mifsk_rx_config *cfg )
 {
     if ( !cfg || cfg->expect_n_bits == 0 || cfg->expect_n_bits > MIFSK_MAX_FRAME_BITS
@@ -278,13 +312,81 @@ extern "C" int mifsk_find_frame_batch( mifsk_ctx *ctx, const mifsk_rx_config *cf
 					  nproblems, stream);
 }
 
+// --auto-carrier (minimodem.c:1179-1220): scan every stream for its mark tone on
+// the device, fetch the bands, give each stream the twiddle table of its own
+// (mark, space) pair, then run the receive loop from where the scan stopped.
+// One host round trip in the middle, so this path synchronises `stream` once.
+static int demod_batch_auto( mifsk_ctx *ctx, const mifsk_rx_config *cfg, const DevCfg &d,
+	const DevCfg *d_cfg, const double *d_tw_default, const mifsk_demod_io *io, void *stream )
+{
+    const size_t ns = (size_t)io->nstreams;
+    if ( ctx->auto_cap < ns ) {
+	if ( ctx->d_auto_band ) (void)hipFree(ctx->d_auto_band);
+	if ( ctx->d_auto_start ) (void)hipFree(ctx->d_auto_start);
+	if ( ctx->d_auto_tw ) (void)hipFree(ctx->d_auto_tw);
+	ctx->d_auto_band = nullptr; ctx->d_auto_start = nullptr; ctx->d_auto_tw = nullptr;
+	ctx->auto_cap = 0;
+	if ( hipMalloc(&ctx->d_auto_band, ns * sizeof(int32_t)) != hipSuccess
+		|| hipMalloc(&ctx->d_auto_start, ns * sizeof(uint32_t)) != hipSuccess
+		|| hipMalloc(&ctx->d_auto_tw, ns * sizeof(double *)) != hipSuccess )
+	    return -ENOMEM;
+	ctx->auto_cap = ns;
+    }
+    const double *d_cs = nullptr;
+    int rc = get_cs(ctx, (unsigned)cfg->fftsize, &d_cs);
+    if ( rc )
+	return rc;
+    // default negative shift, in the reference's float arithmetic (minimodem.c:1203-1206)
+    int b_shift = - (float)( cfg->autodetect_shift + cfg->band_width / 2.0f ) / cfg->band_width;
+    if ( cfg->inverted_freqs )
+	b_shift *= -1;
+    if ( b_shift == 0 )
+	return -EINVAL;			// assert in fsk_set_tones_by_bandshift (fsk.c:587)
+    mifsk::CarrierScanArgs a;
+    a.d_samples = io->d_samples;
+    a.stream_stride = io->stream_stride;
+    a.d_nsamples = io->d_nsamples;
+    a.nsamples = io->nsamples;
+    a.nstreams = io->nstreams;
+    a.d_cs = d_cs;
+    a.fftsize = (uint32_t)cfg->fftsize;
+    a.nbands = cfg->nbands;
+    a.nsamples_per_scan = cfg->nsamples_per_bit > (float)cfg->fftsize ? (float)cfg->fftsize
+								       : cfg->nsamples_per_bit;
+    a.threshold = cfg->auto_carrier_threshold;
+    a.samplebuf_size = cfg->samplebuf_size;
+    a.b_shift = b_shift;
+    a.d_band = ctx->d_auto_band;
+    a.d_start = ctx->d_auto_start;
+    rc = mifsk::launch_carrier_scan(a, stream);
+    if ( rc )
+	return rc;
+    std::vector<int32_t> band(ns);
+    HIP_OK(hipMemcpyAsync(band.data(), ctx->d_auto_band, ns * sizeof(int32_t),
+			  hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+    std::vector<const double *> tw(ns, d_tw_default);
+    for ( size_t s = 0; s < ns; s++ ) {
+	if ( band[s] < 0 )
+	    continue;
+	rc = get_twiddles(ctx, TwKey{(unsigned)cfg->fftsize, (unsigned)band[s],
+				     (unsigned)( band[s] + b_shift ), cfg->bit_nsamples}, &tw[s]);
+	if ( rc )
+	    return rc;
+    }
+    HIP_OK(hipMemcpy(ctx->d_auto_tw, tw.data(), ns * sizeof(double *), hipMemcpyHostToDevice));
+    if ( io->d_carrier_band )
+	HIP_OK(hipMemcpyAsync(io->d_carrier_band, ctx->d_auto_band, ns * sizeof(int32_t),
+			      hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return mifsk::launch_demod_batch(d, d_cfg, d_tw_default, *io, stream, ctx->d_auto_tw,
+				     ctx->d_auto_start);
+}
+
 extern "C" int mifsk_demod_batch( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
 	const mifsk_demod_io *io, void *stream )
 {
     if ( !ctx || !io || check_cfg(cfg) )
 	return -EINVAL;
-    if ( cfg->auto_carrier_threshold > 0.0f )
-	return -ENOSYS;
     if ( io->nstreams < 0 || ( io->nstreams > 0 && !io->d_samples ) )
 	return -EINVAL;
     if ( io->stream_stride % 4 != 0 || ( (uintptr_t)io->d_samples & 15u ) )
@@ -303,6 +405,8 @@ extern "C" int mifsk_demod_batch( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
     rc = get_devcfg(ctx, d, &d_cfg);
     if ( rc )
 	return rc;
+    if ( cfg->auto_carrier_threshold > 0.0f && io->nstreams > 0 )
+	return demod_batch_auto(ctx, cfg, d, d_cfg, d_tw, io, stream);
     return mifsk::launch_demod_batch(d, d_cfg, d_tw, *io, stream);
 }
 
@@ -367,6 +471,8 @@ extern "C" int mifsk_demod_batch_host( mifsk_ctx *ctx, const mifsk_rx_config *cf
     if ( hio->d_nepisodes ){ if ( d_neps.alloc(ns) ) return -ENOMEM;        io.d_nepisodes = d_neps.p; }
     if ( hio->d_status )   { if ( d_status.alloc(ns) ) return -ENOMEM;      io.d_status = d_status.p; }
     if ( hio->d_counters ) { if ( d_cnt.alloc(ns * MIFSK_NCOUNTERS) ) return -ENOMEM; io.d_counters = d_cnt.p; }
+    DevBuf<int32_t> d_band;
+    if ( hio->d_carrier_band ) { if ( d_band.alloc(ns) ) return -ENOMEM; io.d_carrier_band = d_band.p; }
 
     int rc = mifsk_demod_batch(ctx, cfg, &io, nullptr);
     if ( rc )
@@ -381,6 +487,8 @@ extern "C" int mifsk_demod_batch_host( mifsk_ctx *ctx, const mifsk_rx_config *cf
     if ( hio->d_nepisodes )HIP_OK(hipMemcpy(hio->d_nepisodes, d_neps.p, ns * sizeof(uint32_t), hipMemcpyDeviceToHost));
     if ( hio->d_status )   HIP_OK(hipMemcpy(hio->d_status, d_status.p, ns * sizeof(uint32_t), hipMemcpyDeviceToHost));
     if ( hio->d_counters ) HIP_OK(hipMemcpy(hio->d_counters, d_cnt.p, ns * MIFSK_NCOUNTERS * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if ( hio->d_carrier_band && cfg->auto_carrier_threshold > 0.0f )
+	HIP_OK(hipMemcpy(hio->d_carrier_band, d_band.p, ns * sizeof(int32_t), hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -548,21 +656,9 @@ extern "C" int fsk_detect_carrier( fsk_plan *p, float *samples, unsigned int nsa
     if ( hipSetDevice(ctx->device) != hipSuccess )
 	return -1;
     const unsigned N = (unsigned)p->fftsize;
-    if ( ctx->cs_fftsize != N ) {
-	std::vector<double> h(2 * (size_t)N);
-	for ( unsigned k = 0; k < N; k++ ) {
-	    const double ang = 2.0 * M_PI * (double)k / (double)N;
-	    h[2 * (size_t)k] = std::cos(ang);
-	    h[2 * (size_t)k + 1] = -std::sin(ang);
-	}
-	if ( ctx->d_cs ) (void)hipFree(ctx->d_cs);
-	ctx->d_cs = nullptr;
-	ctx->cs_fftsize = 0;
-	if ( hipMalloc(&ctx->d_cs, h.size() * sizeof(double)) != hipSuccess
-		|| hipMemcpy(ctx->d_cs, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess )
-	    return -1;
-	ctx->cs_fftsize = N;
-    }
+    const double *d_cs = nullptr;
+    if ( get_cs(ctx, N, &d_cs) )
+	return -1;
     if ( legacy_reserve(lp, nsamples) )
 	return -1;
     if ( lp->cap_mags < p->nbands ) {
@@ -575,7 +671,7 @@ extern "C" int fsk_detect_carrier( fsk_plan *p, float *samples, unsigned int nsa
     }
     if ( hipMemcpy(lp->d_samples, samples, nsamples * sizeof(float), hipMemcpyHostToDevice) != hipSuccess )
 	return -1;
-    if ( mifsk::launch_detect_carrier(lp->d_samples, nsamples, ctx->d_cs, N, p->nbands,
+    if ( mifsk::launch_detect_carrier(lp->d_samples, nsamples, d_cs, N, p->nbands,
 				      lp->d_mags, nullptr) )
 	return -1;
     std::vector<float> mags(p->nbands);

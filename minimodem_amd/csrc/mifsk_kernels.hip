@@ -32,6 +32,7 @@
 #include <cstdint>
 
 #include "mifsk_device.h"
+#include "mifsk_devmath.h"
 
 // cycle timers for tools/counters.py; off in the production build because
 // each s_memtime read costs the serial wave a round trip
@@ -50,17 +51,6 @@ constexpr int W_CAP = 448;	// bit windows per batch (LDS scratch)
 // ---------------------------------------------------------------------------
 // arithmetic shared by every kernel
 // ---------------------------------------------------------------------------
-
-// |X[b]| * scalar, as the reference computes it (fsk.c:107-114): the FFT output
-// is a pair of floats; hypotf in glibc 2.35 is exactly
-// (float)sqrt((double)re*re + (double)im*im) (verified exhaustively on the
-// host, tests/test_host_math.py); f64 sqrt on gfx950 is correctly rounded.
-__device__ __forceinline__ float band_mag( double re, double im, float scalar )
-{
-    const float fr = (float)re, fi = (float)im;
-    const double s = (double)fr * (double)fr + (double)fi * (double)fi;
-    return (float)sqrt(s) * scalar;
-}
 
 struct FrameOut {
     float	conf;
@@ -1005,7 +995,8 @@ __device__ __forceinline__ float lane_bcast( float v, uint32_t src )
 // The reference's receive loop (minimodem.c:1137-1463); executed by wave 0 only.
 template <bool USE_SLAB>
 __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__restrict__ tw,
-	const mifsk_demod_io &io, uint32_t slab_cap, uint32_t lat_frames, StreamLds *lds )
+	const mifsk_demod_io &io, uint32_t slab_cap, uint32_t lat_frames, uint32_t base0,
+	StreamLds *lds )
 {
     const uint32_t s = blockIdx.x;
     const float *x = io.d_samples + (size_t)s * io.stream_stride;
@@ -1031,7 +1022,7 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
     uint32_t advance = 0;
     float track_amplitude = 0.0f, peak_confidence = 0.0f;
 
-    uint32_t base = 0;			// absolute index of samplebuf[0]
+    uint32_t base = base0 < N ? base0 : N;	// absolute index of samplebuf[0]
     uint32_t n_out_frames = 0, n_out_bytes = 0, n_out_eps = 0, ep_first = 0;
     uint32_t status = 0;
     uint32_t n_iter = 0, n_bulk = 0, n_refine = 0;
@@ -1633,9 +1624,15 @@ template <bool USE_SLAB>
 __global__ __launch_bounds__(BLOCK, 4)
 void demod_kernel( const DevCfg *__restrict__ cfgp, const double *__restrict__ tw,
 	mifsk_demod_io io, uint32_t slab_cap, uint32_t lat_frames, uint32_t lat_rounds,
-	uint32_t region_floats, uint32_t region_cap )
+	uint32_t region_floats, uint32_t region_cap,
+	const double *const *__restrict__ tw_v, const uint32_t *__restrict__ start_v )
 {
     StreamLds *lds = reinterpret_cast<StreamLds *>(mifsk_smem);
+    // --auto-carrier: this stream's own tone pair (table) and the cursor the
+    // search starts at, both found by carrier_scan_kernel (mifsk_carrier.hip)
+    if ( tw_v )
+	tw = tw_v[blockIdx.x];
+    const uint32_t base0 = start_v ? start_v[blockIdx.x] : 0u;
     // the configuration lives in device memory (uniform -> scalar loads); it is
     // NOT a by-value kernel argument so that the worker body below can be a real
     // function with its own register allocation
@@ -1663,7 +1660,7 @@ void demod_kernel( const DevCfg *__restrict__ cfgp, const double *__restrict__ t
 	// the serial chain is the critical path of the workgroup: let it win
 	// issue arbitration against the (throughput-bound) worker waves
 	__builtin_amdgcn_s_setprio(3);
-	master_loop<USE_SLAB>(cfg, tw, io, slab_cap, lat_frames * lat_rounds, lds);
+	master_loop<USE_SLAB>(cfg, tw, io, slab_cap, lat_frames * lat_rounds, base0, lds);
     } else {
 	worker_main<USE_SLAB>(cfgp, tw, lds, io.d_samples + (size_t)blockIdx.x * io.stream_stride,
 			      n_own, slab_cap, lat_frames, region_floats, region_cap, safe_limit,
@@ -1722,7 +1719,8 @@ static constexpr size_t kLdsHeader = offsetof(StreamLds, slab);
 static constexpr size_t kLdsPerCu = 160 * 1024;
 
 int launch_demod_batch( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_tw,
-	const mifsk_demod_io &io, void *stream )
+	const mifsk_demod_io &io, void *stream,
+	const double *const *d_tw_v, const uint32_t *d_start_v )
 {
     if ( io.nstreams <= 0 )
 	return 0;
@@ -1814,10 +1812,10 @@ int launch_demod_batch( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_
 	    return hip_rc(e);
 	hipLaunchKernelGGL(demod_kernel<true>, dim3((unsigned)io.nstreams), dim3(BLOCK),
 			   lds_bytes, st, d_cfg, d_tw, io, slab_cap, lat_frames, lat_rounds,
-			   (uint32_t)region_floats, region_cap);
+			   (uint32_t)region_floats, region_cap, d_tw_v, d_start_v);
     } else {
 	hipLaunchKernelGGL(demod_kernel<false>, dim3((unsigned)io.nstreams), dim3(BLOCK),
-			   kLdsHeader + 16, st, d_cfg, d_tw, io, 0u, 0u, 1u, 0u, 0u);
+			   kLdsHeader + 16, st, d_cfg, d_tw, io, 0u, 0u, 1u, 0u, 0u, d_tw_v, d_start_v);
     }
     return hip_rc(hipGetLastError());
 }

@@ -86,9 +86,12 @@ def test_demod_matches_oracle_and_reference_on_goldens(gpu, name):
     # device frame bits + episodes -> host post-pass (mifsk_stream_text) == everything the
     # reference printed: stdout through its databits decoder (ascii, baudot, caller-ID,
     # binary, print filter) and the CARRIER / NOCARRIER lines on stderr
+    if cfg.auto_carrier_threshold > 0:          # --auto-carrier: the band found, and the space band with it
+        assert int(res["carrier_band"][0]) == ref["carrier_band"] >= 0
     out, err = M.stream_text(cfg, res["bits"][0, :int(res["nframes"][0])],
                              res["episodes"][0, :int(res["nepisodes"][0])],
-                             print_filter="--print-filter" in g["rx_args"])
+                             print_filter="--print-filter" in g["rx_args"],
+                             b_mark=int(res["carrier_band"][0]) if "carrier_band" in res else None)
     assert out == g["stdout"]
     elines = [l for l in err.splitlines() if l]
     assert [l for l in elines if l.startswith("### CARRIER")] == g["carrier"]
@@ -205,6 +208,42 @@ def test_random_batch_with_noise_matches_oracle(gpu, mode):
         assert_stream_equal(res, i, ref, mode)
         total += len(ref["frames"])
     assert total > 10 * nwords
+
+
+@pytest.mark.parametrize("mode,tones", [
+    ("300", [(1270, 1070), (1570, 1370), (2025, 1825), (980, 780), (3000, 2800)]),
+    ("1200", [(1200, 2200), (1500, 2300), (2000, 2800), (1000, 1800), (2600, 3400)]),
+])
+def test_auto_carrier_batch_with_different_tones_per_stream(gpu, mode, tones):
+    """--auto-carrier over a batch whose streams use different tone pairs, behind
+    different amounts of leading silence and noise; plus streams in which no
+    carrier is ever found.  Band, start cursor and everything decoded after
+    them must equal the oracle's, stream by stream."""
+    M, torch, ctx = gpu
+    cfg = M.rx_config(mode, auto_carrier_threshold=0.001)
+    ocfg = O.oracle_config(mode, auto_carrier_threshold=0.001)
+    rng = np.random.default_rng(99)
+    streams = []
+    for i, (mark, space) in enumerate(tones):
+        txcfg = M.rx_config(mode, mark_f=float(mark), space_f=float(space))
+        words = rng.integers(32, 127, size=30 + i, dtype=np.uint8)
+        x = M.synthesize(txcfg, words, leading_silence=int(rng.integers(0, 30000)),
+                         amplitude=float(rng.uniform(0.3, 1.0)))
+        if i % 2:
+            x = (x + rng.normal(0, 0.0002, x.shape)).astype(np.float32)   # below the threshold
+        streams.append(x)
+    streams.append(np.zeros(40000, np.float32))                          # silence: never found
+    streams.append(rng.normal(0, 0.0001, 30000).astype(np.float32))      # noise below the threshold
+    streams.append(np.zeros(0, np.float32))
+    streams.append(np.zeros(17, np.float32))                             # shorter than a scan window
+    res = run_gpu_streams(M, torch, ctx, cfg, streams)
+    found = 0
+    for i, s in enumerate(streams):
+        ref = O.oracle_rx_stream(ocfg, s, ring_mode=False)
+        assert int(res["carrier_band"][i]) == ref["carrier_band"], (mode, i)
+        assert_stream_equal(res, i, ref, mode)
+        found += ref["carrier_band"] >= 0
+    assert found == len(tones)
 
 
 def test_output_capacity_overflow_is_flagged(gpu):
