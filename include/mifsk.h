@@ -330,6 +330,19 @@ long mifsk_tx_synthesize( const mifsk_rx_config *cfg, const uint8_t *words, size
 	unsigned sin_table_len, float amplitude, unsigned leading_silence, int as_s16,
 	float *out, size_t out_cap );
 
+/* The same generator for a whole batch on the device: stream s is
+ * d_words[s][0 .. nwords[s]) (uniform `nwords` when d_nwords is NULL) behind
+ * leading_silence[s] zero samples, written to d_out[s][..out_stride) with the rest
+ * of the row zeroed; d_nsamples_out[s] receives its length (which may exceed
+ * out_stride: the row is then cut).  Table-lookup mode only (-ENOTSUP for
+ * sin_table_len == 0, i.e. --lut=0, which needs the host's sinf).  Bit-identical
+ * to mifsk_tx_synthesize.  Asynchronous on `stream`. */
+int mifsk_tx_synthesize_batch( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
+	const uint8_t *d_words, size_t words_stride, const uint32_t *d_nwords, uint32_t nwords,
+	int nstreams, unsigned sin_table_len, float amplitude,
+	const uint32_t *d_leading_silence, uint32_t leading_silence, int as_s16,
+	float *d_out, size_t out_stride, uint32_t *d_nsamples_out, void *stream );
+
 #ifdef __cplusplus
 }
 #endif

@@ -428,3 +428,37 @@ def ingest_rxnoise(ctx, samples, rxnoise, nsamples=None, stream=None):
     if rc != 0:
         raise RuntimeError("mifsk_ingest_rxnoise_f32 -> %d" % rc)
     return samples
+
+
+def synthesize_batch(ctx, cfg, words, nwords=None, lut=4096, amplitude=1.0, leading_silence=0,
+                     s16=False, stride=None, stream=None):
+    """The transmitter for a whole batch on the device (mifsk_tx_synthesize_batch):
+    words is a torch.uint8 CUDA tensor [nstreams, max_words]; nwords / leading_silence
+    may be int32 CUDA tensors [nstreams] or scalars.  Returns (samples float32
+    [nstreams, stride], lengths int32 [nstreams]); rows are zero after their length."""
+    torch = _torch()
+    assert words.is_cuda and words.dtype == torch.uint8 and words.dim() == 2
+    nstreams, width = words.shape
+    nw_t = nwords if torch.is_tensor(nwords) else None
+    nw_u = int(width if nwords is None else (0 if nw_t is not None else nwords))
+    ls_t = leading_silence if torch.is_tensor(leading_silence) else None
+    ls_u = 0 if ls_t is not None else int(leading_silence)
+    if stride is None:
+        max_lead = int(ls_t.max()) if ls_t is not None and nstreams else ls_u
+        max_words = int(nw_t.max()) if nw_t is not None and nstreams else nw_u
+        one = np.zeros(max(1, max_words), np.uint8)
+        n = _lib.load().mifsk_tx_synthesize(C.byref(cfg), one.ctypes.data, max_words, lut,
+                                            C.c_float(amplitude), max_lead, 0, None, 0)
+        stride = (max(int(n), 4) + 3) & ~3
+    out = torch.empty((nstreams, stride), dtype=torch.float32, device=words.device)
+    lens = torch.zeros(nstreams, dtype=torch.int32, device=words.device)
+    rc = _lib.load().mifsk_tx_synthesize_batch(
+        ctx.handle, C.byref(cfg), C.c_void_p(words.data_ptr()),
+        words.stride(0) if nstreams > 1 else width,
+        C.c_void_p(nw_t.data_ptr()) if nw_t is not None else None, nw_u, nstreams, int(lut),
+        C.c_float(amplitude), C.c_void_p(ls_t.data_ptr()) if ls_t is not None else None, ls_u,
+        1 if s16 else 0, C.c_void_p(out.data_ptr()), stride, C.c_void_p(lens.data_ptr()),
+        _stream_ptr(torch, stream))
+    if rc != 0:
+        raise RuntimeError("mifsk_tx_synthesize_batch -> %d" % rc)
+    return out, lens

@@ -165,6 +165,7 @@ EXPORTS = [
     "mifsk_databits_create", "mifsk_databits_destroy", "mifsk_databits_reset",
     "mifsk_databits_decode", "mifsk_stream_text",
     "mifsk_wav_parse", "mifsk_ingest_s16", "mifsk_ingest_rxnoise_f32",
+    "mifsk_tx_synthesize_batch",
 ]
 
 _lib = None
@@ -236,5 +237,10 @@ def load():
     lib.mifsk_ingest_rxnoise_f32.restype = C.c_int
     lib.mifsk_ingest_rxnoise_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                              C.c_uint32, C.c_int, C.c_float, C.c_void_p]
+    lib.mifsk_tx_synthesize_batch.restype = C.c_int
+    lib.mifsk_tx_synthesize_batch.argtypes = [
+        C.c_void_p, C.POINTER(RxConfig), C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_int,
+        C.c_uint, C.c_float, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p,
+        C.c_void_p]
     _lib = lib
     return lib
