@@ -1026,7 +1026,7 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
     uint32_t n_out_frames = 0, n_out_bytes = 0, n_out_eps = 0, ep_first = 0;
     uint32_t status = 0;
     uint32_t n_iter = 0, n_bulk = 0, n_refine = 0;
-    uint32_t cyc_bulk = 0;
+    uint32_t cyc_bulk = 0, cyc_general = 0, cyc_restart = 0, cyc_s1 = 0, cyc_s2 = 0;
     const uint32_t t_start = MIFSK_CLOCK();
 
     const ZigZag zc0(cfg.try_first[0], cfg.try_max[0], cfg.try_step[0]);
@@ -1184,14 +1184,17 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 	if ( avail == 0 || avail < cfg.expect_nsamples )
 	    break;
 	n_iter++;
+	const uint32_t t_gen = MIFSK_CLOCK();
 
 	const uint32_t ci = carrier ? 1u : 0u;
 	const uint32_t try_max = cfg.try_max[ci];
 	const uint32_t try_step = cfg.try_step[ci];
 	const uint32_t try_first = cfg.try_first[ci];
 
+	const uint32_t t_s1 = MIFSK_CLOCK();
 	ScanResult sr = ctx.scan(base, carrier ? zc1 : zc0, try_first, cfg.search_limit,
 				 carrier ? 0u : 1u);		// minimodem.c:1265-1274
+	cyc_s1 += MIFSK_CLOCK() - t_s1;
 	float confidence = sr.conf;
 	float amplitude = sr.ampl;
 	uint64_t bits = sr.bits;
@@ -1249,7 +1252,9 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 	if ( refine && confidence < INFINITY && try_step > 1u ) {	// minimodem.c:1357-1389
 	    // `carrier` is already set: an acquiring frame is re-searched with
 	    // the data string over the no-carrier range (minimodem.c:1378)
+	    const uint32_t t_s2 = MIFSK_CLOCK();
 	    ScanResult s2 = ctx.scan(base, ci ? zf1 : zf0, try_first, INFINITY, 0u);
+	    cyc_s2 += MIFSK_CLOCK() - t_s2;
 	    flags |= MIFSK_FRAME_REFINED;
 	    n_refine++;
 	    if ( s2.conf > confidence ) {
@@ -1303,9 +1308,12 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 	    const uint32_t p = base + advance + cfg.try_first[1];
 	    const bool cached = __ballot(lane >= lds->c_q && lane < lds->c_n
 					 && lds->c_kind == 0u && lds->c_pos[lane] == p) != 0ULL;
+	    const uint32_t t_ls = MIFSK_CLOCK();
 	    if ( !cached && !( ctx.inflight && ctx.inflight_anchor == p ) )
 		ctx.lattice_start(p);
+	    cyc_restart += MIFSK_CLOCK() - t_ls;
 	}
+	cyc_general += MIFSK_CLOCK() - t_gen;
     }
 
     if ( carrier ) {						// minimodem.c:1469-1474
@@ -1348,6 +1356,10 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 	    c[MIFSK_CNT_CYC_WAIT] = ctx.cyc_wait;
 	    c[MIFSK_CNT_CYC_CONFIDENCE] = ctx.cyc_conf;
 	    c[MIFSK_CNT_CYC_BULK] = cyc_bulk;
+	    c[16] = cyc_general;	// general iterations that produced a frame (profile build)
+	    c[17] = cyc_restart;
+	    c[18] = cyc_s1;
+	    c[19] = cyc_s2;
 	}
 	ctx.next_cmd()->op = CMD_EXIT;
     }
