@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Randomised parity soak (run on the GPU box): many streams per mode with random
+payloads, amplitudes, leading silence, additive noise, DC offset, clipping, rate
+slop (resampled TX rate) and truncation; every frame record and episode from the
+device must equal the oracle's bit for bit.   python tools/soak.py [--seed N] [--streams N]"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import _oracle as O          # noqa: E402  (the checker)
+import minimodem_amd as M    # noqa: E402
+
+MODES = [("1200", {}), ("300", {}), ("12000", {}), ("same", {}), ("rtty", {}), ("tdd", {}),
+         ("1200", dict(n_data_bits=7)), ("1200", dict(msb_first=1)), ("2400", {}),
+         ("1200", dict(sample_rate=44100)), ("600", dict(nstopbits=2.0)),
+         ("1200", dict(auto_carrier_threshold=0.001)), ("300", dict(auto_carrier_threshold=0.001))]
+
+
+def make_stream(rng, cfg, mode):
+    slow = mode in ("rtty", "tdd")
+    nwords = int(rng.integers(1, 12 if slow else 120))
+    hi = 1 << min(8, int(cfg.n_data_bits))
+    words = rng.integers(0, hi, size=nwords, dtype=np.uint8)
+    # rate slop: transmit at a slightly different baud rate than the receiver expects
+    txcfg = cfg
+    if rng.random() < 0.3:
+        txcfg = M.rx_config(mode if not mode.replace(".", "").isdigit()
+                            else str(float(mode) * float(rng.uniform(0.985, 1.015))))
+        if txcfg.n_data_bits != cfg.n_data_bits:
+            txcfg = cfg
+    x = M.synthesize(txcfg, words, amplitude=float(rng.uniform(0.05, 1.0)),
+                     leading_silence=int(rng.integers(0, 3000)), s16=bool(rng.integers(0, 2)))
+    r = rng.random()
+    if r < 0.5:
+        x = x + rng.normal(0, float(rng.choice([0.001, 0.02, 0.1, 0.3])), x.shape)
+    if rng.random() < 0.15:
+        x = x + float(rng.uniform(-0.3, 0.3))              # DC offset
+    if rng.random() < 0.1:
+        x = np.clip(x, -0.2, 0.2)                          # clipping
+    if rng.random() < 0.15:
+        x = x[: int(len(x) * rng.uniform(0.2, 0.95))]      # cut mid-stream
+    if rng.random() < 0.05:
+        x = np.concatenate([x, np.zeros(int(rng.integers(1, 20000))), x])   # two bursts
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--streams", type=int, default=96)
+    args = ap.parse_args()
+    import torch
+    ctx = M.Context(0)
+    rng = np.random.default_rng(args.seed)
+    total_frames = bad = 0
+    for mode, kw in MODES:
+        cfg = M.rx_config(mode, **kw)
+        ocfg = O.oracle_config(mode, **kw)
+        streams = [make_stream(rng, cfg, mode) for _ in range(args.streams)]
+        maxn = max(len(s) for s in streams)
+        stride = (maxn + 3) & ~3
+        host = np.zeros((len(streams), stride), np.float32)
+        lens = np.zeros(len(streams), np.int32)
+        for i, s in enumerate(streams):
+            host[i, :len(s)] = s
+            lens[i] = len(s)
+        t = time.time()
+        res = M.results_to_host(M.demod_batch(ctx, cfg, torch.from_numpy(host).cuda(),
+                                              nsamples=torch.from_numpy(lens).cuda(),
+                                              want=("bytes", "frames", "episodes"), episodes_cap=64))
+        nf = 0
+        for i, s in enumerate(streams):
+            ref = O.oracle_rx_stream(ocfg, s, ring_mode=False)
+            n, ne = int(res["nframes"][i]), int(res["nepisodes"][i])
+            ok = (n == len(ref["frames"]) and ne == len(ref["episodes"])
+                  and res["frames"][i, :n].tobytes() == ref["frames"].tobytes()
+                  and res["episodes"][i, :ne].tobytes() == ref["episodes"].tobytes()
+                  and res["bytes"][i, :int(res["nbytes"][i])].tobytes() == ref["bytes"])
+            if not ok:
+                bad += 1
+                print("MISMATCH mode %s %r stream %d (len %d): gpu %d frames, oracle %d"
+                      % (mode, kw, i, len(s), n, len(ref["frames"])))
+            nf += n
+        total_frames += nf
+        print("%-6s %-40s %4d streams %7d frames  %.1f s" % (mode, kw, len(streams), nf, time.time() - t))
+    print("seed %d: %d frames compared, %d mismatching streams" % (args.seed, total_frames, bad))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
