@@ -76,6 +76,11 @@ void fill_devcfg( DevCfg &d, const mifsk_rx_config &c )
     for ( unsigned k = 0; k < c.expect_n_bits; k++ )
 	if ( c.bit_offset[k] % 4 != 0 )
 	    d.lat_linear = 0;
+    d.lat_grid = ( d.lat_linear && c.expect_n_bits >= 2
+		   && d.lock_advance == ( c.expect_n_bits - 1 ) * c.bit_nsamples ) ? 1u : 0u;
+    for ( unsigned k = 0; k < c.expect_n_bits; k++ )
+	if ( c.bit_offset[k] != k * c.bit_nsamples )
+	    d.lat_grid = 0;
     for ( unsigned k = 0; k < c.expect_n_bits; k++ ) {
 	d.bit_offset[k] = c.bit_offset[k];
 	for ( int s = 0; s < 2; s++ ) {

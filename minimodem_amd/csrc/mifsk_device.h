@@ -35,7 +35,11 @@ struct DevCfg {
     uint32_t	nbits_magic;		// floor(2^32 / n_bits)
     uint32_t	lock_back;		// slab row 0 sits this far before a locked frame's first try
     uint32_t	lat_linear;		// lattice windows all start on 16-byte boundaries of their region
-    uint32_t	pad1;
+    // the windows of consecutive locked frames tile one grid of bit lengths
+    // (bit_offset[k] = k B, lock_advance = (n_bits - 1) B): the last window of a
+    // frame IS the first window of the next, and a round of F frames has only
+    // F (n_bits - 1) + 1 distinct windows
+    uint32_t	lat_grid;
     uint32_t	bit_offset[MIFSK_MAX_FRAME_BITS];	// fsk.c:204
     // expect strings as bit masks, [0]=data [1]=sync: bit k of req_mask is set
     // when bit k of the frame is required ('0'/'1'), req_val holds its value

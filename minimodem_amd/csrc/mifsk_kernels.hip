@@ -753,6 +753,7 @@ struct Master {
     uint32_t		slab_cap;	// SCAN: samples the whole slab can hold
     uint32_t		slab_lo, slab_hi;	// SCAN: absolute range currently staged
     uint32_t		lat_batch;	// LATTICE: frames per batch = per round x rounds (0 = off)
+    uint32_t		conf_idx;	// LATTICE: where this lane's frame starts in mags[buf][]
     uint32_t		lane;
     // the lattice batch the workers are computing right now
     bool		inflight;
@@ -763,10 +764,18 @@ struct Master {
     uint32_t		cyc_par = 0, cyc_conf = 0, cyc_wait = 0;
 
     __device__ __forceinline__ Master( const DevCfg &c, const double *t, const float *xs,
-	    uint32_t n, StreamLds *l, uint32_t cap, uint32_t lf )
+	    uint32_t n, StreamLds *l, uint32_t cap, uint32_t lf, uint32_t lat_round )
 	: cfg(c), tw(t), x(xs), N(n), lds(l), slab_cap(cap), slab_lo(0), slab_hi(0),
 	  lat_batch(lf), lane(threadIdx.x), inflight(false), inflight_anchor(0),
-	  inflight_frames(0), inflight_buf(0), seq(0) {}
+	  inflight_frames(0), inflight_buf(0), seq(0)
+    {
+	// frame `lane` of a batch = frame (lane % lat_round) of round (lane / lat_round)
+	conf_idx = lane * cfg.n_bits;
+	if ( cfg.lat_grid && lat_round ) {
+	    const uint32_t r = lane / lat_round, fr = lane - r * lat_round;
+	    conf_idx = r * ( lat_round * ( cfg.n_bits - 1u ) + 1u ) + fr * ( cfg.n_bits - 1u );
+	}
+    }
 
     // the slot for the command that the NEXT barrier publishes
     __device__ __forceinline__ StreamLds::Cmd *next_cmd() { return &lds->cmd[seq & 1u]; }
@@ -822,7 +831,7 @@ struct Master {
 	cyc_wait += t_c - t_w;
 	n_lattice++;
 	if ( lane < frames ) {
-	    const FrameOut fo = frame_confidence(&lds->mags[buf][lane * cfg.n_bits],
+	    const FrameOut fo = frame_confidence(&lds->mags[buf][conf_idx],
 						 cfg.req_mask[0], cfg.req_val[0], cfg.n_bits);
 	    lds->c_conf[lane] = fo.conf;
 	    lds->c_ampl[lane] = fo.ampl;
@@ -995,8 +1004,8 @@ __device__ __forceinline__ float lane_bcast( float v, uint32_t src )
 // The reference's receive loop (minimodem.c:1137-1463); executed by wave 0 only.
 template <bool USE_SLAB>
 __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__restrict__ tw,
-	const mifsk_demod_io &io, uint32_t slab_cap, uint32_t lat_frames, uint32_t base0,
-	StreamLds *lds )
+	const mifsk_demod_io &io, uint32_t slab_cap, uint32_t lat_frames, uint32_t lat_round,
+	uint32_t base0, StreamLds *lds )
 {
     const uint32_t s = blockIdx.x;
     const float *x = io.d_samples + (size_t)s * io.stream_stride;
@@ -1011,7 +1020,7 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
     const uint32_t lane = threadIdx.x;
     const bool t0 = lane == 0;
 
-    Master<USE_SLAB> ctx(cfg, tw, x, N, lds, slab_cap, lat_frames);
+    Master<USE_SLAB> ctx(cfg, tw, x, N, lds, slab_cap, lat_frames, lat_round);
 
     // reference loop state (minimodem.c:1079-1088,1132-1133), uniform in the wave
     bool carrier = false;
@@ -1461,7 +1470,7 @@ __device__ __forceinline__ void correlate_linear_asm( const double *tw, const fl
 
 __device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const double *__restrict__ tw,
 	StreamLds *lds, const StreamLds::Cmd *cmd, const float *__restrict__ x, uint32_t N,
-	uint32_t region_floats, uint32_t lat_frames, uint32_t wkr, uint32_t done,
+	uint32_t region_floats, uint32_t lat_frames, uint32_t wkr, uint32_t done, uint32_t win_base,
 	uint32_t rel_lane, uint32_t safe_limit,
 	float4 (&pbuf)[STAGE_VEC], uint32_t &pref_org4, uint32_t (&wcyc)[3] )
 {
@@ -1477,7 +1486,8 @@ __device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const 
 	const uint32_t t_in = MIFSK_CLOCK();
 	const uint32_t frames = total - done < lat_frames ? total - done : lat_frames;
 	const uint32_t anchor = cmd->anchor + done * cfg.lock_advance;
-	const uint32_t nwin = frames * n_bits;
+	// distinct windows of the round (cfg.lat_grid: consecutive frames share one)
+	const uint32_t nwin = cfg.lat_grid ? frames * ( n_bits - 1u ) + 1u : frames * n_bits;
 	const uint32_t w = wkr * 64u + lane;
 	if ( wkr * 64u >= nwin ) {
 	    pref_org4 = 0xFFFFFFFFu;
@@ -1560,7 +1570,7 @@ __device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const 
 	double mr = 0.0, mi = 0.0, sr = 0.0, si = 0.0;
 	correlate_linear_asm(tw, region + ( a - lo ), ( B + XCH - 1 ) / XCH, mr, mi, sr, si);
 	if ( active )
-	    lds->mags[buf][done * n_bits + w] = make_float2(band_mag(mr, mi, cfg.magscalar),
+	    lds->mags[buf][win_base + w] = make_float2(band_mag(mr, mi, cfg.magscalar),
 							   band_mag(sr, si, cfg.magscalar));
 	wave_lds_sync();			// the region is rewritten by the next round
 	const uint32_t t_out = MIFSK_CLOCK();
@@ -1585,8 +1595,12 @@ __device__ __forceinline__ void worker_main( const DevCfg *__restrict__ cfgp,
     if ( USE_SLAB && cfg.lat_linear ) {
 	const uint32_t w = wkr * 64u + ( threadIdx.x & 63u );
 	const uint32_t f = udiv_magic(w, cfg.n_bits, cfg.nbits_magic);
-	rel_lane = f * cfg.lock_advance + cfg.bit_offset[( w - f * cfg.n_bits ) & 63u];
+	rel_lane = cfg.lat_grid ? w * cfg.bit_nsamples
+				: f * cfg.lock_advance + cfg.bit_offset[( w - f * cfg.n_bits ) & 63u];
     }
+    // windows a full round writes into mags[]: rounds of one batch sit back to back
+    const uint32_t wins_per_round = cfg.lat_grid ? lat_frames * ( cfg.n_bits - 1u ) + 1u
+						 : lat_frames * cfg.n_bits;
     float4 pbuf[STAGE_VEC];
 #pragma unroll
     for ( int i = 0; i < STAGE_VEC; i++ )
@@ -1613,9 +1627,10 @@ __device__ __forceinline__ void worker_main( const DevCfg *__restrict__ cfgp,
 	    if ( cfg.lat_linear ) {
 		// rounds of lat_frames frames (what the regions hold)
 		const uint32_t total = cmd->frames;
-		for ( uint32_t done = 0; done < total; done += lat_frames )
+		uint32_t win_base = 0;
+		for ( uint32_t done = 0; done < total; done += lat_frames, win_base += wins_per_round )
 		    worker_lattice_linear(cfg, tw, lds, cmd, x, N, region_floats, lat_frames,
-					  wkr, done, rel_lane, safe_limit, pbuf, pref_org4, wcyc);
+					  wkr, done, win_base, rel_lane, safe_limit, pbuf, pref_org4, wcyc);
 	    } else
 		worker_lattice(cfg, tw, lds, cmd, x, N, region_floats, region_cap, lat_frames,
 			       wkr, pbuf, pref_org4, wcyc);
@@ -1672,7 +1687,7 @@ void demod_kernel( const DevCfg *__restrict__ cfgp, const double *__restrict__ t
 	// the serial chain is the critical path of the workgroup: let it win
 	// issue arbitration against the (throughput-bound) worker waves
 	__builtin_amdgcn_s_setprio(3);
-	master_loop<USE_SLAB>(cfg, tw, io, slab_cap, lat_frames * lat_rounds, base0, lds);
+	master_loop<USE_SLAB>(cfg, tw, io, slab_cap, lat_frames * lat_rounds, lat_frames, base0, lds);
     } else {
 	worker_main<USE_SLAB>(cfgp, tw, lds, io.d_samples + (size_t)blockIdx.x * io.stream_stride,
 			      n_own, slab_cap, lat_frames, region_floats, region_cap, safe_limit,
@@ -1749,6 +1764,12 @@ int launch_demod_batch( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_
     // LATTICE geometry: `frames` per batch so that the windows fill the worker
     // lanes; each worker wave's region must hold the samples its 64 windows span
     auto region_samples = [&]( uint32_t frames ) -> uint32_t {
+	if ( cfg.lat_grid ) {
+	    // one grid of bit lengths: a wave's 64 windows span 64 B samples; the
+	    // chunked correlator overruns the last window only when B % XCH != 0
+	    const uint32_t nwin = frames * ( cfg.n_bits - 1u ) + 1u;
+	    return ( nwin < 64u ? nwin : 64u ) * B + ( B % XCH ? XCH : 0u );
+	}
 	const uint32_t nwin = frames * cfg.n_bits;
 	uint32_t worst = 0, prev = 0;
 	for ( uint32_t w = 0; w < nwin; w++ ) {		// the kernel relies on ordered starts
@@ -1768,14 +1789,14 @@ int launch_demod_batch( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_
 	}
 	return ( worst + 4 + XCH + 3 ) & ~3u;	// + alignment head + one chunk of overrun
     };
-    uint32_t lat_frames = LAT_LANES / cfg.n_bits;
+    uint32_t lat_frames = cfg.lat_grid ? ( LAT_LANES - 1u ) / ( cfg.n_bits - 1u ) : LAT_LANES / cfg.n_bits;
     if ( lat_frames > P_CAP ) lat_frames = P_CAP;
     uint32_t region_cap = 0;
     size_t region_floats = 0;
     while ( lat_frames ) {
 	region_cap = region_samples(lat_frames);
 	region_floats = floats_for(region_cap);
-	if ( region_cap <= 64u * STAGE_VEC * 4u - 4u && kLdsHeader + NWORKERS * region_floats * 4 <= budget_small
+	if ( region_cap <= 64u * STAGE_VEC * 4u - ( cfg.lat_grid ? 0u : 4u ) && kLdsHeader + NWORKERS * region_floats * 4 <= budget_small
 		&& NWORKERS * region_floats >= floats_for(reach + 4) )
 	    break;
 	lat_frames--;
@@ -1787,8 +1808,10 @@ int launch_demod_batch( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_
     uint32_t lat_rounds = 1;
     if ( lat_frames && cfg.lat_linear ) {
 	lat_rounds = 2;
+	const uint32_t wins_per_round = cfg.lat_grid ? lat_frames * ( cfg.n_bits - 1u ) + 1u
+						     : lat_frames * cfg.n_bits;
 	while ( lat_rounds > 1 && ( lat_frames * lat_rounds > P_CAP
-				    || lat_frames * lat_rounds * cfg.n_bits > W_CAP ) )
+				    || wins_per_round * lat_rounds > W_CAP ) )
 	    lat_rounds--;
     }
 
