@@ -305,10 +305,7 @@ struct StreamLds {
     float	c_conf[P_CAP];
     float	c_ampl[P_CAP];
     uint32_t	c_pos[P_CAP];
-    uint32_t	c_n;		// valid cache entries
-    uint32_t	c_kind;		// expect string they were evaluated with
-    uint32_t	c_q;		// entries [c_q, c_n) are consecutive lattice frames
-    uint32_t	pad;
+    uint32_t	pad[4];		// (which entries are valid is the master's private state)
     // Two command slots used alternately: the one published before barrier
     // number n is slot n & 1, so a slot is rewritten only after every wave has
     // passed another barrier and is done reading it.
@@ -759,6 +756,9 @@ struct Master {
     bool		inflight;
     uint32_t		inflight_anchor, inflight_frames, inflight_buf;
     uint32_t		seq;		// barriers that published a command so far
+    // scored lattice frames held in lds->c_conf/c_ampl/c_bits[0 .. lat_n): entry e
+    // is the frame whose first try sits at lat_anchor + e * lock_advance
+    uint32_t		lat_n, lat_anchor;
     // work counters (written out only when the caller asked for them)
     uint32_t		n_batches = 0, n_stages = 0, n_hits = 0, n_positions = 0, n_lattice = 0;
     uint32_t		cyc_par = 0, cyc_conf = 0, cyc_wait = 0;
@@ -767,7 +767,7 @@ struct Master {
 	    uint32_t n, StreamLds *l, uint32_t cap, uint32_t lf, uint32_t lat_round )
 	: cfg(c), tw(t), x(xs), N(n), lds(l), slab_cap(cap), slab_lo(0), slab_hi(0),
 	  lat_batch(lf), lane(threadIdx.x), inflight(false), inflight_anchor(0),
-	  inflight_frames(0), inflight_buf(0), seq(0)
+	  inflight_frames(0), inflight_buf(0), seq(0), lat_n(0), lat_anchor(0)
     {
 	// frame `lane` of a batch = frame (lane % lat_round) of round (lane / lat_round)
 	conf_idx = lane * cfg.n_bits;
@@ -775,6 +775,16 @@ struct Master {
 	    const uint32_t r = lane / lat_round, fr = lane - r * lat_round;
 	    conf_idx = r * ( lat_round * ( cfg.n_bits - 1u ) + 1u ) + fr * ( cfg.n_bits - 1u );
 	}
+    }
+
+    // index of the scored lattice frame whose first try is at p, or ~0u
+    __device__ __forceinline__ uint32_t lattice_lookup( uint32_t p ) const
+    {
+	if ( !lat_n || p < lat_anchor )
+	    return ~0u;
+	const uint32_t d = p - lat_anchor;
+	const uint32_t e = udiv_magic(d, cfg.lock_advance, cfg.la_magic);
+	return ( e < lat_n && e * cfg.lock_advance == d ) ? e : ~0u;
     }
 
     // the slot for the command that the NEXT barrier publishes
@@ -836,13 +846,9 @@ struct Master {
 	    lds->c_conf[lane] = fo.conf;
 	    lds->c_ampl[lane] = fo.ampl;
 	    lds->c_bits[lane] = fo.bits;
-	    lds->c_pos[lane] = anchor + lane * cfg.lock_advance;
 	}
-	if ( lane == 0 ) {
-	    lds->c_n = frames;
-	    lds->c_q = 0;
-	    lds->c_kind = 0;
-	}
+	lat_n = frames;
+	lat_anchor = anchor;
 	wave_lds_sync();
 	cyc_conf += MIFSK_CLOCK() - t_c;
     }
@@ -894,12 +900,11 @@ struct Master {
 	    return r;
 	const uint32_t p0 = base + first;
 
-	// cache probe for the first candidate
+	// the first candidate may be a lattice frame that is already scored
+	// (those are scored against the data string)
 	{
-	    const bool m = lane < lds->c_n && lds->c_kind == kind && lds->c_pos[lane] == p0;
-	    const unsigned long long b = __ballot(m);
-	    if ( b ) {
-		const int hit = __ffsll((long long)b) - 1;
+	    const uint32_t hit = kind == 0u ? lattice_lookup(p0) : ~0u;
+	    if ( hit != ~0u ) {
 		const float c = lds->c_conf[hit];
 		if ( c > 0.0f && c >= limit ) {		// fsk.c:492,499
 		    r.conf = c;
@@ -926,11 +931,7 @@ struct Master {
 	    }
 	    if ( lane < Q )
 		lds->c_pos[lane] = base + zz.at(c0 + lane);
-	    if ( lane == 0 ) {
-		lds->c_n = Q;
-		lds->c_q = Q;		// nothing here is a lattice frame
-		lds->c_kind = kind;
-	    }
+	    lat_n = 0;			// the SCAN's scores overwrite the lattice frames'
 	    evaluate(Q, kind, base + tlo, base + thi + cfg.last_reach);
 	    for ( uint32_t i = 0; i < Q; i++ ) {	// fsk.c:492-501
 		const float c = lds->c_conf[i];
@@ -1035,7 +1036,7 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
     uint32_t n_out_frames = 0, n_out_bytes = 0, n_out_eps = 0, ep_first = 0;
     uint32_t status = 0;
     uint32_t n_iter = 0, n_bulk = 0, n_refine = 0;
-    uint32_t cyc_bulk = 0, cyc_general = 0, cyc_restart = 0, cyc_s1 = 0, cyc_s2 = 0;
+    uint32_t cyc_bulk = 0, cyc_general = 0, cyc_restart = 0, cyc_s1 = 0, cyc_s2 = 0, cyc_dpp = 0;
     const uint32_t t_start = MIFSK_CLOCK();
 
     const ZigZag zc0(cfg.try_first[0], cfg.try_max[0], cfg.try_step[0]);
@@ -1058,13 +1059,10 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 	    const uint32_t first = cfg.try_first[1];
 	    const uint32_t nb = base + advance;		// cursor of the next iteration
 	    const uint32_t p = nb + first;
-	    const uint32_t cn = lds->c_n, cq = lds->c_q;
-	    const bool m = lane >= cq && lane < cn && lds->c_kind == 0u && lds->c_pos[lane] == p;
-	    const unsigned long long bal = __ballot(m);
+	    const uint32_t e0 = ctx.lattice_lookup(p);
 	    bool progressed = false;
-	    if ( bal ) {
-		const uint32_t e0 = (uint32_t)__ffsll((long long)bal) - 1u;
-		uint32_t K = cn - e0;
+	    if ( e0 != ~0u ) {
+		uint32_t K = ctx.lat_n - e0;
 		// frame k sits at cursor nb + k*lock_advance and needs expect_nsamples from there
 		const uint32_t fn = cfg.frame_nsamples;
 		const uint32_t la = cfg.lock_advance;
@@ -1086,6 +1084,7 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 		const float cp = wave_shr1(cv), ap = wave_shr1(av);
 		float my_t = track_amplitude, my_pk = peak_confidence;
 		float my_sc = confidence_total, my_sa = amplitude_total;
+		const uint32_t t_dpp = MIFSK_CLOCK();
 		for ( uint32_t k = 1; k < K; k++ ) {
 		    const float pt = wave_shr1(my_t), ppk = wave_shr1(my_pk);
 		    const float psc = wave_shr1(my_sc), psa = wave_shr1(my_sa);
@@ -1098,6 +1097,7 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 		    my_sc = lane ? nsc : my_sc;
 		    my_sa = lane ? nsa : my_sa;
 		}
+		cyc_dpp += MIFSK_CLOCK() - t_dpp;
 		// ... and the state after frame k
 		const float t = ( my_t + av ) / 2.0f;
 		const float pk = my_pk < cv ? cv : my_pk;
@@ -1315,8 +1315,7 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 	// flight or already scored
 	if ( ctx.lat_batch && advance <= N - base ) {
 	    const uint32_t p = base + advance + cfg.try_first[1];
-	    const bool cached = __ballot(lane >= lds->c_q && lane < lds->c_n
-					 && lds->c_kind == 0u && lds->c_pos[lane] == p) != 0ULL;
+	    const bool cached = ctx.lattice_lookup(p) != ~0u;
 	    const uint32_t t_ls = MIFSK_CLOCK();
 	    if ( !cached && !( ctx.inflight && ctx.inflight_anchor == p ) )
 		ctx.lattice_start(p);
@@ -1369,6 +1368,7 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 	    c[17] = cyc_restart;
 	    c[18] = cyc_s1;
 	    c[19] = cyc_s2;
+	    c[20] = cyc_dpp;
 	}
 	ctx.next_cmd()->op = CMD_EXIT;
     }
@@ -1665,11 +1665,6 @@ void demod_kernel( const DevCfg *__restrict__ cfgp, const double *__restrict__ t
     // function with its own register allocation
     const DevCfg &cfg = *cfgp;
 
-    if ( threadIdx.x == 0 ) {
-	lds->c_n = 0;
-	lds->c_q = 0;
-	lds->c_kind = 0;
-    }
     lds_barrier();
 
     // How far this stream's row may be over-read (in samples from its start)
