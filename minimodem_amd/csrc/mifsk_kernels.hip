@@ -996,6 +996,61 @@ __device__ __forceinline__ float wave_shr1( float v )
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, i, 0x138, 0xf, 0xf, false));
 }
 
+// The lane scan of the bulk replay (master_loop): `steps` = K - 1 applications of
+//   t <- (t[l-1] + a) * 0.5, pk <- max(pk[l-1], c), sc <- sc[l-1] + c, sa <- sa[l-1] + a
+// with the lower neighbour read through DPP wave_shr:1.  Ping-pong between two
+// register sets (the DPP source is never the destination); lane 0 is left alone
+// by every DPP instruction (no valid source, bound_ctrl off), and `tmp` holds
+// 2 * t in lane 0 so that the plain multiply reproduces its t.  v_max_f32 is the
+// reference's `if (pk < c) pk = c` for every input that can occur (pk is never
+// NaN; a NaN c leaves pk alone in both).  Asm because the compiler neither folds
+// the shuffles into the arithmetic nor keeps lane 0 out of it (15 instructions
+// per step instead of 5).
+// Finally b* (seeded by the caller with the state before frame 0) receive the
+// lower neighbour's result, i.e. the state BEFORE each lane's frame -- inside the
+// asm as well: around a DPP intrinsic the compiler narrows EXEC to the lanes whose
+// result is used, and a lane whose SOURCE lane is masked off is not written.
+__device__ __forceinline__ void replay_scan_asm( float &xt, float &xpk, float &xsc, float &xsa,
+	float &bt, float &bpk, float &bsc, float &bsa, float cv, float av, uint32_t K )
+{
+    float yt = xt, ypk = xpk, ysc = xsc, ysa = xsa;
+    float tmp = xt + xt;
+    const uint32_t pairs = K / 2u;		// 2 * pairs >= K - 1 steps
+#define MIFSK_SCAN_STEP(ST, SPK, SSC, SSA, DT, DPK, DSC, DSA)						\
+	"v_add_f32_dpp %[tmp], " ST ", %[av] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"		\
+	"v_mul_f32_e32 " DT ", 0.5, %[tmp]\n\t"	/* >= 2 instructions before DT is read by DPP */	\
+	"v_max_f32_dpp " DPK ", " SPK ", %[cv] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"		\
+	"v_add_f32_dpp " DSC ", " SSC ", %[cv] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"		\
+	"v_add_f32_dpp " DSA ", " SSA ", %[av] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+    uint32_t n = pairs;
+    // s_nop: a VGPR written by a VALU instruction may be read through DPP only two
+    // wait states later, and the compiler's hazard recogniser does not look into
+    // (or out of) an asm block
+    asm volatile(
+	"s_nop 1\n\t"
+	"s_cmp_eq_u32 %[n], 0\n\t"
+	"s_cbranch_scc1 2f\n\t"
+	"1:\n\t"
+	MIFSK_SCAN_STEP("%[xt]", "%[xpk]", "%[xsc]", "%[xsa]", "%[yt]", "%[ypk]", "%[ysc]", "%[ysa]")
+	"s_sub_u32 %[n], %[n], 1\n\t"
+	MIFSK_SCAN_STEP("%[yt]", "%[ypk]", "%[ysc]", "%[ysa]", "%[xt]", "%[xpk]", "%[xsc]", "%[xsa]")
+	"s_cmp_lg_u32 %[n], 0\n\t"
+	"s_cbranch_scc1 1b\n\t"
+	"s_nop 1\n\t"
+	"2:\n\t"
+	"v_mov_b32_dpp %[bt], %[xt] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+	"v_mov_b32_dpp %[bpk], %[xpk] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+	"v_mov_b32_dpp %[bsc], %[xsc] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+	"v_mov_b32_dpp %[bsa], %[xsa] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+	"s_nop 1\n\t"
+	: [bt] "+v"(bt), [bpk] "+v"(bpk), [bsc] "+v"(bsc), [bsa] "+v"(bsa), [xt] "+v"(xt), [xpk] "+v"(xpk), [xsc] "+v"(xsc), [xsa] "+v"(xsa),
+	  [yt] "+v"(yt), [ypk] "+v"(ypk), [ysc] "+v"(ysc), [ysa] "+v"(ysa),
+	  [tmp] "+v"(tmp), [n] "+s"(n)
+	: [cv] "v"(cv), [av] "v"(av)
+	: "scc");
+#undef MIFSK_SCAN_STEP
+}
+
 __device__ __forceinline__ float lane_bcast( float v, uint32_t src )
 {
     return __builtin_bit_cast(float,
@@ -1074,35 +1129,26 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 		const float cv = have ? lds->c_conf[e0 + lane] : 0.0f;
 		const float av = have ? lds->c_ampl[e0 + lane] : 0.0f;
 		// Replay the f32 state recurrences over all K candidates without
-		// branching.  Lane k wants the state as it was BEFORE frame k:
-		//   S_0 = current state,  S_k = step(S_{k-1}, c_{k-1}, a_{k-1}).
-		// Every lane applies step() to its lower neighbour's state (DPP
-		// wave_shr:1) and that neighbour's (c, a); after j rounds lanes
-		// 0..j are final, so K - 1 rounds settle lanes 0..K-1.  Same f32
-		// operations in the same order as the scalar loop, no cross-lane
-		// reads through SGPRs.  Lane 0 (S_0) is never changed.
-		const float cp = wave_shr1(cv), ap = wave_shr1(av);
+		// branching, as a lane scan.  Lane k computes the state AFTER frame k,
+		//   A_k = step(A_{k-1}, c_k, a_k),   A_{-1} = the current state,
+		// by applying step() to its lower neighbour's state (DPP wave_shr:1).
+		// Lane 0 has no lower neighbour: with bound_ctrl off the DPP
+		// instructions leave its destination alone, so it keeps the A_0 it
+		// is seeded with.  After j steps lanes 0..j are final; K - 1 steps
+		// settle lanes 0..K-1 (further steps change nothing).  Same f32
+		// operations in the same order as the scalar loop.
+		const uint32_t t_dpp = MIFSK_CLOCK();
+		float xt = ( track_amplitude + av ) / 2.0f;		// minimodem.c:1391
+		float xpk = peak_confidence < cv ? cv : peak_confidence;	// :1392-1393
+		float xsc = confidence_total + cv;			// :1397-1398
+		float xsa = amplitude_total + av;
+		// ... and the state before frame `lane`: the lower neighbour's "after";
+		// lane 0 keeps what these are seeded with, the current state
 		float my_t = track_amplitude, my_pk = peak_confidence;
 		float my_sc = confidence_total, my_sa = amplitude_total;
-		const uint32_t t_dpp = MIFSK_CLOCK();
-		for ( uint32_t k = 1; k < K; k++ ) {
-		    const float pt = wave_shr1(my_t), ppk = wave_shr1(my_pk);
-		    const float psc = wave_shr1(my_sc), psa = wave_shr1(my_sa);
-		    const float nt = ( pt + ap ) / 2.0f;	// minimodem.c:1391
-		    const float npk = ppk < cp ? cp : ppk;	// minimodem.c:1392-1393
-		    const float nsc = psc + cp;			// minimodem.c:1397-1398
-		    const float nsa = psa + ap;
-		    my_t = lane ? nt : my_t;
-		    my_pk = lane ? npk : my_pk;
-		    my_sc = lane ? nsc : my_sc;
-		    my_sa = lane ? nsa : my_sa;
-		}
+		replay_scan_asm(xt, xpk, xsc, xsa, my_t, my_pk, my_sc, my_sa, cv, av, K);
 		cyc_dpp += MIFSK_CLOCK() - t_dpp;
-		// ... and the state after frame k
-		const float t = ( my_t + av ) / 2.0f;
-		const float pk = my_pk < cv ? cv : my_pk;
-		const float sc = my_sc + cv;
-		const float sa = my_sa + av;
+		const float t = xt, pk = xpk, sc = xsc, sa = xsa;	// state after frame `lane`
 		const bool ok = have
 		    && cv > 0.0f && cv >= cfg.search_limit	// fsk.c:492,499: first try ends the scan
 		    && !( cv < my_pk * 0.75f )			// minimodem.c:1278
