@@ -141,6 +141,86 @@ frame_confidence( const float2 *mags, uint64_t req_mask, uint64_t req_val, uint3
     return out;
 }
 
+// The same for a frame length known at compile time: every magnitude is loaded
+// once (all loads in flight together), the per-bit signal levels stay in
+// registers for the divergence pass, nothing is computed for padding slots.
+// Operation for operation the sequence above.
+template <int NB>
+__device__ __forceinline__ FrameOut
+frame_confidence_fixed( const float2 *mags, uint64_t req_mask, uint64_t req_val )
+{
+    FrameOut out;
+    out.conf = 0.0f;
+    out.ampl = 0.0f;
+    out.bits = 0;
+
+    float2 m[NB];
+#pragma unroll
+    for ( int k = 0; k < NB; k++ )
+	m[k] = mags[k];
+    uint32_t bits = 0;					// NB <= 32 here
+    float sig[NB];
+    float total_sig = 0.0f, total_noise = 0.0f;
+    float mark_sig = 0.0f, space_sig = 0.0f;
+    uint32_t n_mark = 0;
+#pragma unroll
+    for ( int k = 0; k < NB; k++ ) {
+	const bool one = m[k].x > m[k].y;		// fsk.c:161 (strict)
+	sig[k] = one ? m[k].x : m[k].y;
+	const float noise = one ? m[k].y : m[k].x;
+	bits |= ( one ? 1u : 0u ) << k;
+	total_sig += sig[k];				// fsk.c:278
+	if ( noise > FLT_EPSILON )			// fsk.c:279
+	    total_noise += noise;
+	if ( one ) {
+	    mark_sig += sig[k];
+	    n_mark++;
+	} else {
+	    space_sig += sig[k];
+	}
+    }
+    if ( ( (uint64_t)bits ^ req_val ) & req_mask )	// fsk.c:211-212,486-487
+	return out;
+    const uint32_t n_space = (uint32_t)NB - n_mark;
+
+    const float snr = total_sig / total_noise;		// fsk.c:292
+    const float avg_sig = total_sig / (float)NB;	// fsk.c:295
+    if ( n_mark )
+	mark_sig /= (float)n_mark;			// fsk.c:298-301
+    if ( n_space )
+	space_sig /= (float)n_space;
+
+    float term[NB];					// fsk.c:305-313
+#pragma unroll
+    for ( int k = 0; k < NB; k++ ) {
+	const float cls = ( bits >> k ) & 1u ? mark_sig : space_sig;
+	term[k] = fabsf(sig[k] - cls) / cls;
+    }
+    float divergence = 0.0f;
+#pragma unroll
+    for ( int k = 0; k < NB; k++ )
+	divergence += term[k];
+    divergence *= 2.0f;
+    divergence /= (float)NB;
+
+    out.conf = snr * (1.0f - divergence);		// fsk.c:336
+    out.ampl = avg_sig;					// fsk.c:342
+    out.bits = bits;					// fsk.c:439-441
+    return out;
+}
+
+// frame lengths with a specialised confidence pass: start + 8 data + stop with
+// the previous stop bit (11), the 7-bit variant (10); everything else is generic
+__device__ __forceinline__ FrameOut
+frame_confidence_any( const float2 *mags, uint64_t req_mask, uint64_t req_val, uint32_t n_bits )
+{
+    if ( n_bits == 11u )
+	return frame_confidence_fixed<11>(mags, req_mask, req_val);
+    if ( n_bits == 10u )
+	return frame_confidence_fixed<10>(mags, req_mask, req_val);
+    return frame_confidence(mags, req_mask, req_val, n_bits);
+}
+
 // The reference's zig-zag scan order (fsk.c:477-484): first, first+s, first-s,
 // first+2s, first-2s, ...; an up-step reaching try_max ends the scan, a
 // down-step below 0 is skipped.  Closed form: U up-positions (u = 0..U-1),
@@ -841,8 +921,8 @@ struct Master {
 	cyc_wait += t_c - t_w;
 	n_lattice++;
 	if ( lane < frames ) {
-	    const FrameOut fo = frame_confidence(&lds->mags[buf][conf_idx],
-						 cfg.req_mask[0], cfg.req_val[0], cfg.n_bits);
+	    const FrameOut fo = frame_confidence_any(&lds->mags[buf][conf_idx],
+						     cfg.req_mask[0], cfg.req_val[0], cfg.n_bits);
 	    lds->c_conf[lane] = fo.conf;
 	    lds->c_ampl[lane] = fo.ampl;
 	    lds->c_bits[lane] = fo.bits;
@@ -880,7 +960,7 @@ struct Master {
 	const uint32_t t_conf = MIFSK_CLOCK();
 	cyc_par += t_conf - t_par;
 	if ( lane < nq ) {
-	    const FrameOut f = frame_confidence(&lds->mags[0][lane * cfg.n_bits],
+	    const FrameOut f = frame_confidence_any(&lds->mags[0][lane * cfg.n_bits],
 						cfg.req_mask[kind], cfg.req_val[kind], cfg.n_bits);
 	    lds->c_conf[lane] = f.conf;
 	    lds->c_ampl[lane] = f.ampl;
