@@ -721,7 +721,11 @@ __device__ __forceinline__ void worker_lattice( const DevCfg &cfg, const double 
 	float4 (&pbuf)[STAGE_VEC], uint32_t &pref_org4, uint32_t (&wcyc)[3] )
 {
     const uint32_t t_in = MIFSK_CLOCK();
-    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t lane = threadIdx.x & 63u;
+    // opaque per call: otherwise the per-vector offsets derived from it are hoisted
+    // out of the worker's command loop, run out of registers and are SPILLED --
+    // and a scratch reload in the staging phase queues behind every global load
+    asm volatile("" : "+v"(lane));
     const uint32_t n_bits = cfg.n_bits, B = cfg.bit_nsamples;
     const uint32_t anchor = cmd->anchor;
     const uint32_t frames = cmd->frames;
@@ -1600,8 +1604,11 @@ __device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const 
 	uint32_t rel_lane, uint32_t safe_limit,
 	float4 (&pbuf)[STAGE_VEC], uint32_t &pref_org4, uint32_t (&wcyc)[3] )
 {
-    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t lane = threadIdx.x & 63u;
+    asm volatile("" : "+v"(lane));	// per-round values derived from it are recomputed, not spilled
     const uint32_t n_bits = cfg.n_bits, B = cfg.bit_nsamples;
+    if ( cfg.lat_grid )
+	rel_lane = ( wkr * 64u + lane ) * B;	// (one multiply: cheaper than keeping it live)
     const uint32_t buf = cmd->buf;
     float *region = lds->slab + (size_t)wkr * region_floats;
     // A batch is scored by the master in one go but correlated here in ROUNDS
