@@ -392,7 +392,7 @@ struct StreamLds {
     struct Cmd {
 	uint32_t	op;		// CMD_*
 	uint32_t	nq;		// SCAN: candidates in c_pos[]
-	uint32_t	stage;		// SCAN: restage the slab at row_org first
+	uint32_t	stage;		// SCAN: samples to (re)stage at row_org first (0: none)
 	uint32_t	row_org;	// SCAN: absolute sample index of slab row 0
 	uint32_t	anchor;		// LATTICE: first-try position of frame 0
 	uint32_t	frames;		// LATTICE: frames in the batch
@@ -589,25 +589,28 @@ __device__ __forceinline__ void correlate_window( const DevCfg &cfg, const doubl
     acc[0] = mr; acc[1] = mi; acc[2] = sr; acc[3] = si;
 }
 
-// SCAN: stage samples [row_org, row_org + slab_cap) into the slab (all threads)
+// SCAN: stage samples [row_org, row_org + nstage) into the slab (all threads)
 __device__ __forceinline__ void par_stage( const DevCfg &cfg, StreamLds *lds, const float *__restrict__ x,
-	uint32_t N, uint32_t slab_cap, uint32_t row_org )
+	uint32_t N, uint32_t slab_cap, uint32_t row_org, uint32_t nstage )
 {
     const uint32_t org4 = row_org & ~3u;
     const uint32_t head = row_org - org4;		// 0..3 samples before row 0: dropped
-    const uint32_t nvec = ( slab_cap + head + 3 ) >> 2;
+    const uint32_t nvec = ( nstage + head + 3 ) >> 2;
     for ( uint32_t v0 = 0; v0 < nvec; v0 += BLOCK * STAGE_VEC ) {
 	float4 buf[STAGE_VEC];
-	// all loads of the round in flight before the first LDS write
+	// all loads of the round in flight before the first LDS write; vector
+	// groups wholly past the end are neither loaded nor stored (uniform tests:
+	// a refinement with the carrier held stages a few hundred samples only)
 #pragma unroll
 	for ( int i = 0; i < STAGE_VEC; i++ ) {
 	    const uint32_t v = v0 + i * BLOCK + threadIdx.x;
-	    buf[i] = load4_raw(x, org4 + ( v << 2 ), N);
+	    if ( v0 + i * BLOCK < nvec )
+		buf[i] = load4_raw(x, org4 + ( v << 2 ), N);
 	}
 #pragma unroll
 	for ( int i = 0; i < STAGE_VEC; i++ ) {
 	    const uint32_t v = v0 + i * BLOCK + threadIdx.x;
-	    if ( v < nvec )
+	    if ( v0 + i * BLOCK < nvec && v < nvec )
 		store4_skewed(cfg, lds->slab, slab_cap, v << 2, head, buf[i], org4 + ( v << 2 ), N);
 	}
     }
@@ -657,7 +660,7 @@ __device__ __forceinline__ void scan_part( const DevCfg &cfg, const double *__re
     const uint32_t nq = cmd->nq;
     const uint32_t row_org = cmd->row_org;
     if ( USE_SLAB && cmd->stage ) {
-	par_stage(cfg, lds, x, N, slab_cap, row_org);
+	par_stage(cfg, lds, x, N, slab_cap, row_org, cmd->stage);
 	lds_barrier();
     }
     par_correlate<USE_SLAB>(cfg, tw, lds, x, N, row_org, nq);
@@ -845,7 +848,7 @@ struct Master {
     uint32_t		lat_n, lat_anchor;
     // work counters (written out only when the caller asked for them)
     uint32_t		n_batches = 0, n_stages = 0, n_hits = 0, n_positions = 0, n_lattice = 0;
-    uint32_t		cyc_par = 0, cyc_conf = 0, cyc_wait = 0;
+    uint32_t		cyc_par = 0, cyc_conf = 0, cyc_wait = 0, cyc_scan_wait = 0;
 
     __device__ __forceinline__ Master( const DevCfg &c, const double *t, const float *xs,
 	    uint32_t n, StreamLds *l, uint32_t cap, uint32_t lf, uint32_t lat_round )
@@ -944,14 +947,20 @@ struct Master {
 	if ( USE_SLAB && ( lo < slab_lo || hi > slab_hi ) ) {
 	    restage = true;
 	    slab_lo = lo;
-	    slab_hi = lo + slab_cap;
+	    // Without a carrier (and in modes that have no lattice) the searches
+	    // that follow advance through the stream and reuse what is staged now:
+	    // fill the slab.  With the lattice running, the next SCAN is many
+	    // frames away and the regions overwrite the slab in between: stage
+	    // what this search reads and no more.
+	    const uint32_t need = ( hi - lo + 7u ) & ~3u;
+	    slab_hi = lo + ( ( kind == 0u && lat_batch && need < slab_cap ) ? need : slab_cap );
 	    n_stages++;
 	}
 	StreamLds::Cmd *c = next_cmd();
 	if ( lane == 0 ) {
 	    c->op = CMD_SCAN;
 	    c->nq = nq;
-	    c->stage = restage ? 1u : 0u;
+	    c->stage = restage ? slab_hi - slab_lo : 0u;
 	    c->row_org = slab_lo;
 	}
 	inflight = false;		// the barrier below also retires any batch in flight
@@ -960,6 +969,7 @@ struct Master {
 	const uint32_t t_par = MIFSK_CLOCK();
 	lds_barrier();			// command (and c_pos[]) published
 	seq++;
+	cyc_scan_wait += MIFSK_CLOCK() - t_par;	// = waiting for the batch in flight to retire
 	scan_part<USE_SLAB>(cfg, tw, lds, c, x, N, slab_cap);
 	const uint32_t t_conf = MIFSK_CLOCK();
 	cyc_par += t_conf - t_par;
@@ -1499,6 +1509,7 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 	    c[18] = cyc_s1;
 	    c[19] = cyc_s2;
 	    c[20] = cyc_dpp;
+	    c[21] = ctx.cyc_scan_wait;
 	}
 	ctx.next_cmd()->op = CMD_EXIT;
     }
