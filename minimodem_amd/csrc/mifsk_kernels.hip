@@ -838,6 +838,7 @@ struct Master {
     uint32_t		slab_lo, slab_hi;	// SCAN: absolute range currently staged
     uint32_t		lat_batch;	// LATTICE: frames per batch = per round x rounds (0 = off)
     uint32_t		conf_idx;	// LATTICE: where this lane's frame starts in mags[buf][]
+    uint32_t		lat_first;	// LATTICE: frames of the first batch after a (re)start
     uint32_t		lane;
     // the lattice batch the workers are computing right now
     bool		inflight;
@@ -856,6 +857,7 @@ struct Master {
 	  lat_batch(lf), lane(threadIdx.x), inflight(false), inflight_anchor(0),
 	  inflight_frames(0), inflight_buf(0), seq(0), lat_n(0), lat_anchor(0)
     {
+	lat_first = lat_round;
 	// frame `lane` of a batch = frame (lane % lat_round) of round (lane / lat_round)
 	conf_idx = lane * cfg.n_bits;
 	if ( cfg.lat_grid && lat_round ) {
@@ -903,12 +905,15 @@ struct Master {
 	slab_lo = slab_hi = 0;		// the regions overwrite whatever SCAN had staged
     }
 
-    // Start the pipeline at `anchor` (nothing is in flight).
+    // Start the pipeline at `anchor` (nothing is in flight).  The first batch is
+    // a single worker round: scoring starts one round earlier, the batches
+    // after it are full ones.
     __device__ __forceinline__ void lattice_start( uint32_t anchor )
     {
-	const uint32_t frames = lattice_frames_at(anchor);
+	uint32_t frames = lattice_frames_at(anchor);
 	if ( !frames )
 	    return;
+	frames = frames < lat_first ? frames : lat_first;
 	publish_lattice(anchor, frames, 0);
 	lds_barrier();			// workers pick the command up
 	seq++;
