@@ -377,6 +377,7 @@ void find_frame_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 __device__ __forceinline__ void lds_barrier();
 
 constexpr int NWORKERS = 3;
+enum { LAT_NONE = 0u, LAT_LINEAR = 1u, LAT_DIRECT = 2u };	// how the workers get at the samples
 constexpr int LAT_LANES = NWORKERS * 64;	// bit windows per lattice batch
 
 struct StreamLds {
@@ -385,7 +386,10 @@ struct StreamLds {
     float	c_conf[P_CAP];
     float	c_ampl[P_CAP];
     uint32_t	c_pos[P_CAP];
-    uint32_t	pad[4];		// (which entries are valid is the master's private state)
+    // 1 + number of the LATTICE command whose results are no longer wanted (the
+    // master needs a SCAN): the workers poll it and go straight to the barrier
+    uint32_t	abort;
+    uint32_t	pad[3];		// (which entries are valid is the master's private state)
     // Two command slots used alternately: the one published before barrier
     // number n is slot n & 1, so a slot is rewritten only after every wave has
     // passed another barrier and is done reading it.
@@ -710,122 +714,6 @@ __device__ __forceinline__ uint32_t wave_max_u32( uint32_t v )
     return v;
 }
 
-// LATTICE: one worker wave's share of a batch -- windows [64 wkr, 64 wkr + 64)
-// of frames anchor + f * lock_advance, f < frames.  The wave stages exactly the
-// samples its own windows cover into its private LDS region and correlates
-// them; there is no dependency on the other waves.  Window starts are
-// non-decreasing in window order (checked on the host), so the span is
-// [start of lane 0, start of lane 63 + B).  While it correlates, the loads for
-// the same share of the NEXT batch (the lattice continued) are already in
-// flight into `pbuf`, so HBM latency is off the critical path.
-__device__ __forceinline__ void worker_lattice( const DevCfg &cfg, const double *__restrict__ tw, StreamLds *lds,
-	const StreamLds::Cmd *cmd, const float *__restrict__ x, uint32_t N,
-	uint32_t region_floats, uint32_t region_cap, uint32_t lat_frames, uint32_t wkr,
-	float4 (&pbuf)[STAGE_VEC], uint32_t &pref_org4, uint32_t (&wcyc)[3] )
-{
-    const uint32_t t_in = MIFSK_CLOCK();
-    uint32_t lane = threadIdx.x & 63u;
-    // opaque per call: otherwise the per-vector offsets derived from it are hoisted
-    // out of the worker's command loop, run out of registers and are SPILLED --
-    // and a scratch reload in the staging phase queues behind every global load
-    asm volatile("" : "+v"(lane));
-    const uint32_t n_bits = cfg.n_bits, B = cfg.bit_nsamples;
-    const uint32_t anchor = cmd->anchor;
-    const uint32_t frames = cmd->frames;
-    const uint32_t nwin = frames * n_bits;
-    const uint32_t buf = cmd->buf;
-    const uint32_t w = wkr * 64u + lane;
-    if ( wkr * 64u >= nwin ) {
-	pref_org4 = 0xFFFFFFFFu;
-	return;					// nothing for this wave (uniform)
-    }
-    const bool active = w < nwin;
-    const uint32_t wc = active ? w : nwin - 1u;	// idle lanes shadow the last window
-    const uint32_t f = udiv_magic(wc, n_bits, cfg.nbits_magic);
-    const uint32_t k = wc - f * n_bits;
-    const uint32_t a = anchor + f * cfg.lock_advance + cfg.bit_offset[k];
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)a, 63) + B;
-    float *region = lds->slab + (size_t)wkr * region_floats;
-
-    const uint32_t org4 = lo & ~3u;
-    const uint32_t head = lo - org4;
-    const uint32_t nvec = ( hi - org4 + 3 ) >> 2;
-    if ( pref_org4 != org4 ) {
-	// nothing usable in flight: fetch this batch now
-#pragma unroll
-	for ( int i = 0; i < STAGE_VEC; i++ ) {
-	    const uint32_t v = i * 64 + lane;
-	    pbuf[i] = load4_raw(x, org4 + ( v << 2 ), N);
-	}
-    }
-    {
-	// Registers -> skewed LDS rows.  (q, r) = (row, column) of this lane's
-	// first sample; one round later the lane is 256 samples further on, so
-	// both advance by constants.  A round whose 64 float4s all lie inside
-	// [row 0, cap) x [0, N) needs no per-sample guards (uniform test).
-	const uint32_t skew = cfg.skew;
-	const uint32_t dq = udiv_magic(256u, B, cfg.div_magic), dr = 256u - dq * B;
-	const uint32_t first0 = lane << 2;
-	uint32_t q, r;
-	divmod_bit(cfg, first0 >= head ? first0 - head : 0u, q, r);
-#pragma unroll
-	for ( int i = 0; i < STAGE_VEC; i++ ) {
-	    const uint32_t v = i * 64 + lane;
-	    const uint32_t first = v << 2;
-	    const uint32_t vlast = i * 64 + 63u;		// last lane of the round
-	    const bool interior = ( i > 0 || head == 0 ) && B >= 4
-		&& vlast < nvec && ( vlast << 2 ) + 3 - head < region_cap
-		&& org4 + ( vlast << 2 ) + 3 < N;
-	    if ( interior ) {
-		float *d = region + ( first - head ) + q * skew;
-		const float4 sv = pbuf[i];
-		d[0] = sv.x;
-		d[1 + ( r + 1 >= B ? skew : 0u )] = sv.y;
-		d[2 + ( r + 2 >= B ? skew : 0u )] = sv.z;
-		d[3 + ( r + 3 >= B ? skew : 0u )] = sv.w;
-	    } else if ( v < nvec ) {
-		store4_skewed(cfg, region, region_cap, first, head, pbuf[i], org4 + first, N);
-	    }
-	    if ( i > 0 || first0 >= head ) {		// (q, r) tracks first - head once that is >= 0
-		q += dq;
-		r += dr;
-		if ( r >= B ) {
-		    r -= B;
-		    q++;
-		}
-	    } else {
-		divmod_bit(cfg, first0 + 256u - head, q, r);
-	    }
-	}
-    }
-    // The same share of the next batch, assuming the lattice goes on (if it does
-    // not, the data is simply never used).  Issued unconditionally and with no
-    // control flow around it: any join point after the loads makes hipcc drain
-    // vmcnt, which would expose the HBM latency the prefetch is there to hide.
-    // (The host guarantees nvec <= 64 * STAGE_VEC, so there is no tail loop.)
-    {
-	const uint32_t nlo = lo + lat_frames * cfg.lock_advance;
-	const uint32_t norg4 = nlo & ~3u;
-#pragma unroll
-	for ( int i = 0; i < STAGE_VEC; i++ ) {
-	    const uint32_t v = i * 64 + lane;
-	    pbuf[i] = load4_raw(x, norg4 + ( v << 2 ), N);
-	}
-	pref_org4 = norg4;
-    }
-    wave_lds_sync();
-    const uint32_t t_mid = MIFSK_CLOCK();
-
-    double acc[4];
-    correlate_window(cfg, tw, region, a - lo, active, acc);
-    if ( active )
-	lds->mags[buf][w] = make_float2(band_mag(acc[0], acc[1], cfg.magscalar),
-					band_mag(acc[2], acc[3], cfg.magscalar));
-    const uint32_t t_out = MIFSK_CLOCK();
-    wcyc[0] += t_mid - t_in;
-    wcyc[1] += t_out - t_mid;
-}
 
 template <bool USE_SLAB>
 struct Master {
@@ -839,6 +727,14 @@ struct Master {
     uint32_t		lat_batch;	// LATTICE: frames per batch = per round x rounds (0 = off)
     uint32_t		conf_idx;	// LATTICE: where this lane's frame starts in mags[buf][]
     uint32_t		lat_first;	// LATTICE: frames of the first batch after a (re)start
+    // How far to speculate.  `spec` = frames per batch: after a failure, as many
+    // as were accepted from the lattice since the failure before it; doubled
+    // every time a whole batch holds.  (A signal whose first tries keep falling
+    // short of the search limit, or that is refined every few frames, gets
+    // short batches; Bell-202 full ones.)  After `cold` batches in a row that
+    // yielded nothing the lattice pauses.
+    uint32_t		spec, run, cold, pause;
+    uint32_t		spec_floor;	// never fewer frames than this per batch
     uint32_t		lane;
     // the lattice batch the workers are computing right now
     bool		inflight;
@@ -858,6 +754,9 @@ struct Master {
 	  inflight_frames(0), inflight_buf(0), seq(0), lat_n(0), lat_anchor(0)
     {
 	lat_first = lat_round;
+	spec = lat_batch;
+	run = cold = pause = 0;
+	spec_floor = 2;
 	// frame `lane` of a batch = frame (lane % lat_round) of round (lane / lat_round)
 	conf_idx = lane * cfg.n_bits;
 	if ( cfg.lat_grid && lat_round ) {
@@ -914,6 +813,7 @@ struct Master {
 	if ( !frames )
 	    return;
 	frames = frames < lat_first ? frames : lat_first;
+	frames = frames < spec ? frames : spec;
 	publish_lattice(anchor, frames, 0);
 	lds_barrier();			// workers pick the command up
 	seq++;
@@ -925,7 +825,9 @@ struct Master {
     {
 	const uint32_t anchor = inflight_anchor, frames = inflight_frames, buf = inflight_buf;
 	const uint32_t next = anchor + frames * cfg.lock_advance;
-	publish_lattice(next, lattice_frames_at(next), buf ^ 1u);
+	uint32_t nf = lattice_frames_at(next);
+	nf = nf < spec ? nf : spec;
+	publish_lattice(next, nf, buf ^ 1u);
 	const uint32_t t_w = MIFSK_CLOCK();
 	lds_barrier();			// batch `anchor` is complete in mags[buf]
 	seq++;
@@ -968,6 +870,8 @@ struct Master {
 	    c->stage = restage ? slab_hi - slab_lo : 0u;
 	    c->row_org = slab_lo;
 	}
+	if ( inflight && lane == 0 )	// command number seq - 1 is the batch in flight
+	    *(volatile uint32_t *)&lds->abort = seq;
 	inflight = false;		// the barrier below also retires any batch in flight
 	n_batches++;
 	n_positions += nq;
@@ -1160,7 +1064,7 @@ __device__ __forceinline__ float lane_bcast( float v, uint32_t src )
 template <bool USE_SLAB>
 __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__restrict__ tw,
 	const mifsk_demod_io &io, uint32_t slab_cap, uint32_t lat_frames, uint32_t lat_round,
-	uint32_t base0, StreamLds *lds )
+	uint32_t lat_mode, uint32_t base0, StreamLds *lds )
 {
     const uint32_t s = blockIdx.x;
     const float *x = io.d_samples + (size_t)s * io.stream_stride;
@@ -1176,6 +1080,10 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
     const bool t0 = lane == 0;
 
     Master<USE_SLAB> ctx(cfg, tw, x, N, lds, slab_cap, lat_frames, lat_round);
+    // LINEAR rounds are cheap (coalesced staging, short windows): never speculate
+    // less than one round; DIRECT rounds stream whole windows per lane
+    if ( lat_mode == LAT_LINEAR )
+	ctx.spec_floor = lat_round;
 
     // reference loop state (minimodem.c:1079-1088,1132-1133), uniform in the wave
     bool carrier = false;
@@ -1266,6 +1174,15 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 		    peak = lane_bcast(my_pk, n);
 		    ctot = lane_bcast(my_sc, n);
 		    atot = lane_bcast(my_sa, n);
+		}
+		ctx.run += n;
+		if ( n < K ) {			// the lattice broke here: remember how long it held
+		    ctx.spec = ctx.run < ctx.spec_floor ? ctx.spec_floor
+			     : ( ctx.run < ctx.lat_batch ? ctx.run : ctx.lat_batch );
+		    ctx.cold = ctx.run ? 0u : ctx.cold + 1u;
+		    ctx.run = 0;
+		} else if ( e0 + K == ctx.lat_n ) {	// a whole batch held: speculate further
+		    ctx.spec = 2u * ctx.spec < ctx.lat_batch ? 2u * ctx.spec : ctx.lat_batch;
 		}
 		if ( n ) {
 		    // outputs of frames 0..n-1, one lane each
@@ -1462,8 +1379,16 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 	    const uint32_t p = base + advance + cfg.try_first[1];
 	    const bool cached = ctx.lattice_lookup(p) != ~0u;
 	    const uint32_t t_ls = MIFSK_CLOCK();
-	    if ( !cached && !( ctx.inflight && ctx.inflight_anchor == p ) )
-		ctx.lattice_start(p);
+	    if ( ctx.pause ) {
+		ctx.pause--;			// the lattice kept missing: plain searches for a while
+	    } else if ( !cached && !( ctx.inflight && ctx.inflight_anchor == p ) ) {
+		if ( ctx.cold >= 4u ) {
+		    ctx.cold = 0;
+		    ctx.pause = 32;
+		} else {
+		    ctx.lattice_start(p);
+		}
+	    }
 	    cyc_restart += MIFSK_CLOCK() - t_ls;
 	}
 	cyc_general += MIFSK_CLOCK() - t_gen;
@@ -1728,6 +1653,105 @@ __device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const 
     }
 }
 
+// LATTICE, direct variant: any bit length, no LDS.  One lane per bit window as
+// everywhere; the lane streams ITS OWN window straight from global memory, 32
+// bytes (one chunk of 8 samples) per step with the next chunk already in flight,
+// while the twiddles -- the same sample index in every lane -- come through the
+// scalar cache as usual.  Lanes' windows lie a bit length apart, so a step's 64
+// loads touch 64 different 32-byte sectors; four consecutive steps use up each
+// 128-byte line, which the caches hold in between.  Nothing has to fit anywhere:
+// this is what runs RTTY (1056-sample windows), SAME (92.16) and Bell-103 (160),
+// whose windows do not fit the linear variant's regions.  Same sums in the same
+// order as every other correlator.
+__device__ __forceinline__ void twiddle_fetch_ro( const double *t, tw8 &a, tw8 &b, tw8 &c, tw8 &d )
+{
+    // no "memory" clobber: that would make hipcc drain vmcnt, i.e. wait for the
+    // next chunk's samples right after asking for them
+    asm volatile("s_load_dwordx16 %0, %4, 0x0\n\t"
+		 "s_load_dwordx16 %1, %4, 0x40\n\t"
+		 "s_load_dwordx16 %2, %4, 0x80\n\t"
+		 "s_load_dwordx16 %3, %4, 0xc0"
+		 : "=&s"(a), "=&s"(b), "=&s"(c), "=&s"(d)
+		 : "s"(t));
+}
+
+__device__ __forceinline__ void twiddle_wait_ro()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+__device__ __forceinline__ void worker_lattice_direct( const DevCfg &cfg, const double *__restrict__ tw,
+	StreamLds *lds, const StreamLds::Cmd *cmd, const float *__restrict__ x, uint32_t N,
+	uint32_t lat_frames, uint32_t wkr, uint32_t done, uint32_t win_base, uint32_t abort_tag,
+	uint32_t (&wcyc)[3] )
+{
+    const uint32_t t_in = MIFSK_CLOCK();
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_bits = cfg.n_bits, B = cfg.bit_nsamples;
+    const uint32_t total = cmd->frames;
+    const uint32_t frames = total - done < lat_frames ? total - done : lat_frames;
+    const uint32_t anchor = cmd->anchor + done * cfg.lock_advance;
+    const uint32_t nwin = cfg.lat_grid ? frames * ( n_bits - 1u ) + 1u : frames * n_bits;
+    const uint32_t w = wkr * 64u + lane;
+    if ( wkr * 64u >= nwin )
+	return;					// nothing for this wave this round (uniform)
+    const bool active = w < nwin;
+    const uint32_t wc = active ? w : wkr * 64u;	// idle lanes shadow the wave's first window
+    uint32_t a;
+    if ( cfg.lat_grid ) {
+	a = anchor + wc * B;
+    } else {
+	const uint32_t f = udiv_magic(wc, n_bits, cfg.nbits_magic);
+	a = anchor + f * cfg.lock_advance + cfg.bit_offset[( wc - f * n_bits ) & 63u];
+    }
+    const uint32_t Bpad = ( B + XCH - 1u ) & ~(uint32_t)( XCH - 1 );
+    double mr = 0.0, mi = 0.0, sr = 0.0, si = 0.0;
+    if ( __all(a + Bpad <= N && a + Bpad >= a) ) {
+	// every window of the wave (padded to whole chunks) lies inside the stream
+	const float *p = x + a;
+	float4_u c0 = *reinterpret_cast<const float4_u *>(p);
+	float4_u c1 = *reinterpret_cast<const float4_u *>(p + 4);
+	for ( uint32_t n0 = 0; n0 < B; n0 += XCH ) {
+	    float4_u d0 = c0, d1 = c1;
+	    if ( n0 + XCH < B ) {		// uniform: the next chunk, in flight during this one's FMAs
+		d0 = *reinterpret_cast<const float4_u *>(p + n0 + XCH);
+		d1 = *reinterpret_cast<const float4_u *>(p + n0 + XCH + 4);
+	    }
+	    tw8 ta, tb, tc, td;
+	    twiddle_fetch_ro(tw + 4 * (size_t)n0, ta, tb, tc, td);
+	    // long windows: give the batch up between chunks when the master asks
+	    // (the LDS read rides on the wait for the twiddles)
+	    const uint32_t ab = *(volatile uint32_t *)&lds->abort;
+	    twiddle_wait_ro();
+	    if ( ab == abort_tag )
+		return;
+	    MIFSK_FMA4(c0.x, ta, 0);  MIFSK_FMA4(c0.y, ta, 1);
+	    MIFSK_FMA4(c0.z, tb, 0);  MIFSK_FMA4(c0.w, tb, 1);
+	    MIFSK_FMA4(c1.x, tc, 0);  MIFSK_FMA4(c1.y, tc, 1);
+	    MIFSK_FMA4(c1.z, td, 0);  MIFSK_FMA4(c1.w, td, 1);
+	    c0 = d0;
+	    c1 = d1;
+	}
+    } else {
+	// a window reaches the end of the stream: per-sample guarded reads
+	// (samples at or beyond N are 0.0), a handful of rounds per stream
+	for ( uint32_t n = 0; n < B; n++ ) {
+	    const uint32_t idx = a + n;
+	    const double xd = (double)( ( idx < N && idx >= a ) ? x[idx] : 0.0f );
+	    const double *t = tw + 4 * (size_t)n;
+	    mr = fma(xd, t[0], mr);
+	    mi = fma(xd, t[1], mi);
+	    sr = fma(xd, t[2], sr);
+	    si = fma(xd, t[3], si);
+	}
+    }
+    if ( active )
+	lds->mags[cmd->buf][win_base + w] = make_float2(band_mag(mr, mi, cfg.magscalar),
+						       band_mag(sr, si, cfg.magscalar));
+    wcyc[1] += MIFSK_CLOCK() - t_in;
+}
+
 // The worker waves' whole life.  A real (non-inlined) function on purpose: it
 // gets its own register allocation, so the 64 SGPRs of twiddles that the
 // correlator wants in flight do not compete with the master's scalar state.
@@ -1735,13 +1759,13 @@ template <bool USE_SLAB>
 __device__ __forceinline__ void worker_main( const DevCfg *__restrict__ cfgp,
 	const double *__restrict__ tw, StreamLds *lds, const float *__restrict__ x, uint32_t N,
 	uint32_t slab_cap, uint32_t lat_frames, uint32_t region_floats, uint32_t region_cap,
-	uint32_t safe_limit, uint64_t *counters )
+	uint32_t lat_mode, uint32_t safe_limit, uint64_t *counters )
 {
     const DevCfg &cfg = *cfgp;
     const uint32_t wkr = ( threadIdx.x >> 6 ) - 1u;
     // linear LATTICE: start of this lane's window relative to the round's anchor
     uint32_t rel_lane = 0;
-    if ( USE_SLAB && cfg.lat_linear ) {
+    if ( USE_SLAB && lat_mode == LAT_LINEAR ) {
 	const uint32_t w = wkr * 64u + ( threadIdx.x & 63u );
 	const uint32_t f = udiv_magic(w, cfg.n_bits, cfg.nbits_magic);
 	rel_lane = cfg.lat_grid ? w * cfg.bit_nsamples
@@ -1773,16 +1797,25 @@ __device__ __forceinline__ void worker_main( const DevCfg *__restrict__ cfgp,
 	    for ( int i = 0; i < STAGE_VEC; i++ )
 		pbuf[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 	} else if ( USE_SLAB && op == CMD_LATTICE ) {
-	    if ( cfg.lat_linear ) {
+	    if ( lat_mode == LAT_LINEAR ) {
 		// rounds of lat_frames frames (what the regions hold)
 		const uint32_t total = cmd->frames;
 		uint32_t win_base = 0;
+		// (no give-up poll here: a LINEAR batch retires within about a
+		// microsecond of the master asking -- measured)
 		for ( uint32_t done = 0; done < total; done += lat_frames, win_base += wins_per_round )
 		    worker_lattice_linear(cfg, tw, lds, cmd, x, N, region_floats, lat_frames,
 					  wkr, done, win_base, rel_lane, safe_limit, pbuf, pref_org4, wcyc);
-	    } else
-		worker_lattice(cfg, tw, lds, cmd, x, N, region_floats, region_cap, lat_frames,
-			       wkr, pbuf, pref_org4, wcyc);
+	    } else {
+		const uint32_t total = cmd->frames;
+		uint32_t win_base = 0;
+		for ( uint32_t done = 0; done < total; done += lat_frames, win_base += wins_per_round ) {
+		    if ( *(volatile uint32_t *)&lds->abort == seq + 1u )
+			break;
+		    worker_lattice_direct(cfg, tw, lds, cmd, x, N, lat_frames, wkr, done, win_base,
+					  seq + 1u, wcyc);
+		}
+	    }
 	}
     }
 #ifdef MIFSK_PROFILE
@@ -1800,7 +1833,7 @@ template <bool USE_SLAB>
 __global__ __launch_bounds__(BLOCK, 4)
 void demod_kernel( const DevCfg *__restrict__ cfgp, const double *__restrict__ tw,
 	mifsk_demod_io io, uint32_t slab_cap, uint32_t lat_frames, uint32_t lat_rounds,
-	uint32_t region_floats, uint32_t region_cap,
+	uint32_t region_floats, uint32_t region_cap, uint32_t lat_mode,
 	const double *const *__restrict__ tw_v, const uint32_t *__restrict__ start_v )
 {
     StreamLds *lds = reinterpret_cast<StreamLds *>(mifsk_smem);
@@ -1814,6 +1847,8 @@ void demod_kernel( const DevCfg *__restrict__ cfgp, const double *__restrict__ t
     // function with its own register allocation
     const DevCfg &cfg = *cfgp;
 
+    if ( threadIdx.x == 0 )
+	lds->abort = 0;
     lds_barrier();
 
     // How far this stream's row may be over-read (in samples from its start)
@@ -1824,17 +1859,17 @@ void demod_kernel( const DevCfg *__restrict__ cfgp, const double *__restrict__ t
     const uint64_t rows_after = (uint64_t)( io.nstreams - 1 - (int)blockIdx.x ) * io.stream_stride;
     const uint32_t safe_limit = rows_after == 0 ? n_own
 			      : rows_after > 0xFFFF0000ull ? 0xFFFF0000u : (uint32_t)rows_after;
-    if ( cfg.lat_linear && safe_limit < 64u * STAGE_VEC * 4u )
+    if ( lat_mode == LAT_LINEAR && safe_limit < 64u * STAGE_VEC * 4u )
 	lat_frames = 0;
 
     if ( threadIdx.x < 64 ) {
 	// the serial chain is the critical path of the workgroup: let it win
 	// issue arbitration against the (throughput-bound) worker waves
 	__builtin_amdgcn_s_setprio(3);
-	master_loop<USE_SLAB>(cfg, tw, io, slab_cap, lat_frames * lat_rounds, lat_frames, base0, lds);
+	master_loop<USE_SLAB>(cfg, tw, io, slab_cap, lat_frames * lat_rounds, lat_frames, lat_mode, base0, lds);
     } else {
 	worker_main<USE_SLAB>(cfgp, tw, lds, io.d_samples + (size_t)blockIdx.x * io.stream_stride,
-			      n_own, slab_cap, lat_frames, region_floats, region_cap, safe_limit,
+			      n_own, slab_cap, lat_frames, region_floats, region_cap, lat_mode, safe_limit,
 			      io.d_counters ? io.d_counters + (size_t)blockIdx.x * MIFSK_NCOUNTERS : nullptr);
     }
 }
@@ -1905,71 +1940,75 @@ int launch_demod_batch( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_
     // LDS budget: 4 workgroups per CU when the stream count can use them
     const size_t budget_small = kLdsPerCu / 4 - 64;
 
-    // LATTICE geometry: `frames` per batch so that the windows fill the worker
-    // lanes; each worker wave's region must hold the samples its 64 windows span
-    auto region_samples = [&]( uint32_t frames ) -> uint32_t {
-	if ( cfg.lat_grid ) {
-	    // one grid of bit lengths: a wave's 64 windows span 64 B samples; the
-	    // chunked correlator overruns the last window only when B % XCH != 0
-	    const uint32_t nwin = frames * ( cfg.n_bits - 1u ) + 1u;
-	    return ( nwin < 64u ? nwin : 64u ) * B + ( B % XCH ? XCH : 0u );
-	}
-	const uint32_t nwin = frames * cfg.n_bits;
-	uint32_t worst = 0, prev = 0;
-	for ( uint32_t w = 0; w < nwin; w++ ) {		// the kernel relies on ordered starts
-	    const uint32_t a = ( w / cfg.n_bits ) * cfg.lock_advance + cfg.bit_offset[w % cfg.n_bits];
-	    if ( a < prev )
-		return 0xFFFFFFF0u;
-	    prev = a;
-	}
-	for ( uint32_t w0 = 0; w0 < nwin; w0 += 64 ) {
-	    uint32_t lo = 0xFFFFFFFFu, hi = 0;
-	    for ( uint32_t w = w0; w < w0 + 64 && w < nwin; w++ ) {
-		const uint32_t a = ( w / cfg.n_bits ) * cfg.lock_advance + cfg.bit_offset[w % cfg.n_bits];
-		lo = a < lo ? a : lo;
-		hi = a + B > hi ? a + B : hi;
-	    }
-	    worst = hi - lo > worst ? hi - lo : worst;
-	}
-	return ( worst + 4 + XCH + 3 ) & ~3u;	// + alignment head + one chunk of overrun
+    // LATTICE geometry.  A round is as many frames as fill the 192 worker lanes
+    // with distinct bit windows.  LINEAR workers stage their 64 windows' span in
+    // a private LDS region (fastest; needs bit length, offsets and frame step
+    // in multiples of 4 samples and the span to fit ten 16-byte loads per
+    // lane); otherwise DIRECT workers stream each window from global memory.
+    const uint32_t frames_max = cfg.lat_grid ? ( LAT_LANES - 1u ) / ( cfg.n_bits - 1u )
+					     : LAT_LANES / cfg.n_bits;
+    uint32_t lat_frames = frames_max > P_CAP ? P_CAP : frames_max;
+    auto wins_in = [&]( uint32_t frames ) -> uint32_t {
+	return cfg.lat_grid ? frames * ( cfg.n_bits - 1u ) + 1u : frames * cfg.n_bits;
     };
-    uint32_t lat_frames = cfg.lat_grid ? ( LAT_LANES - 1u ) / ( cfg.n_bits - 1u ) : LAT_LANES / cfg.n_bits;
-    if ( lat_frames > P_CAP ) lat_frames = P_CAP;
+    // window starts must not decrease in window order (the workers take the
+    // wave's span from its first and last lane)
+    bool ordered = true;
+    for ( uint32_t w = 1; w < lat_frames * cfg.n_bits; w++ ) {
+	const uint32_t a0 = ( ( w - 1 ) / cfg.n_bits ) * cfg.lock_advance + cfg.bit_offset[( w - 1 ) % cfg.n_bits];
+	const uint32_t a1 = ( w / cfg.n_bits ) * cfg.lock_advance + cfg.bit_offset[w % cfg.n_bits];
+	ordered = ordered && a1 >= a0;
+    }
+    uint32_t lat_mode = lat_frames ? LAT_DIRECT : LAT_NONE;
     uint32_t region_cap = 0;
     size_t region_floats = 0;
-    while ( lat_frames ) {
-	region_cap = region_samples(lat_frames);
+    if ( lat_frames && cfg.lat_linear && ordered ) {
+	// span of the widest wave: 64 windows (or all of them)
+	uint32_t span = 0;
+	if ( cfg.lat_grid ) {
+	    const uint32_t nwin = wins_in(lat_frames);
+	    // the chunked correlator overruns the last window only when B % XCH != 0
+	    span = ( nwin < 64u ? nwin : 64u ) * B + ( B % XCH ? XCH : 0u );
+	} else {
+	    const uint32_t nwin = lat_frames * cfg.n_bits;
+	    for ( uint32_t w0 = 0; w0 < nwin; w0 += 64 ) {
+		const uint32_t wl = w0 + 63 < nwin ? w0 + 63 : nwin - 1;
+		const uint32_t lo = ( w0 / cfg.n_bits ) * cfg.lock_advance + cfg.bit_offset[w0 % cfg.n_bits];
+		const uint32_t hi = ( wl / cfg.n_bits ) * cfg.lock_advance + cfg.bit_offset[wl % cfg.n_bits] + B;
+		span = hi - lo > span ? hi - lo : span;
+	    }
+	    span += XCH;
+	}
+	region_cap = ( span + 3 ) & ~3u;
 	region_floats = floats_for(region_cap);
-	if ( region_cap <= 64u * STAGE_VEC * 4u - ( cfg.lat_grid ? 0u : 4u ) && kLdsHeader + NWORKERS * region_floats * 4 <= budget_small
+	if ( region_cap <= 64u * STAGE_VEC * 4u
+		&& kLdsHeader + NWORKERS * region_floats * 4 <= budget_small
 		&& NWORKERS * region_floats >= floats_for(reach + 4) )
-	    break;
-	lat_frames--;
+	    lat_mode = LAT_LINEAR;
     }
 
-    // the master scores `lat_rounds` rounds at once (only the linear worker
-    // iterates rounds): halves the per-frame cost of everything that is paid
-    // per batch -- the confidence pass, the barrier, the command hand-off
+    // the master scores `lat_rounds` rounds at once: halves the per-frame cost
+    // of everything that is paid per batch -- the confidence pass, the barrier,
+    // the command hand-off
     uint32_t lat_rounds = 1;
-    if ( lat_frames && cfg.lat_linear ) {
+    if ( lat_frames ) {
 	lat_rounds = 2;
-	const uint32_t wins_per_round = cfg.lat_grid ? lat_frames * ( cfg.n_bits - 1u ) + 1u
-						     : lat_frames * cfg.n_bits;
 	while ( lat_rounds > 1 && ( lat_frames * lat_rounds > P_CAP
-				    || wins_per_round * lat_rounds > W_CAP ) )
+				    || wins_in(lat_frames) * lat_rounds > W_CAP ) )
 	    lat_rounds--;
     }
 
     uint32_t slab_cap = 0;
     size_t slab_floats = 0;
     bool use_slab = true;
-    if ( lat_frames ) {
+    if ( lat_mode == LAT_LINEAR ) {
 	slab_floats = NWORKERS * region_floats;
 	// samples the whole slab holds in SCAN mode
 	size_t ns = slab_floats * B / ( B + cfg.skew );
 	ns = ns > 16 ? ns - 16 : 0;
 	slab_cap = (uint32_t)( ns & ~(size_t)3 );
     } else {
-	// long bit windows: no lattice; take as much LDS as one search needs
+	// no regions: the slab serves SCAN only; take what one search needs
 	region_cap = 0;
 	region_floats = 0;
 	const size_t need = kLdsHeader + floats_for(reach + 4) * 4;
@@ -1978,6 +2017,8 @@ int launch_demod_batch( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_
 	    slab_floats = floats_for(slab_cap);
 	} else {
 	    use_slab = false;	// e.g. 0.5 baud: windows of 96000 samples
+	    lat_mode = LAT_NONE;
+	    lat_frames = 0;
 	}
     }
 
@@ -1991,10 +2032,11 @@ int launch_demod_batch( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_
 	    return hip_rc(e);
 	hipLaunchKernelGGL(demod_kernel<true>, dim3((unsigned)io.nstreams), dim3(BLOCK),
 			   lds_bytes, st, d_cfg, d_tw, io, slab_cap, lat_frames, lat_rounds,
-			   (uint32_t)region_floats, region_cap, d_tw_v, d_start_v);
+			   (uint32_t)region_floats, region_cap, lat_mode, d_tw_v, d_start_v);
     } else {
 	hipLaunchKernelGGL(demod_kernel<false>, dim3((unsigned)io.nstreams), dim3(BLOCK),
-			   kLdsHeader + 16, st, d_cfg, d_tw, io, 0u, 0u, 1u, 0u, 0u, d_tw_v, d_start_v);
+			   kLdsHeader + 16, st, d_cfg, d_tw, io, 0u, 0u, 1u, 0u, 0u, (uint32_t)LAT_NONE,
+			   d_tw_v, d_start_v);
     }
     return hip_rc(hipGetLastError());
 }
