@@ -375,6 +375,7 @@ void find_frame_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 // ---------------------------------------------------------------------------
 
 __device__ __forceinline__ void lds_barrier();
+__device__ __forceinline__ float lane_bcast( float v, uint32_t src );
 
 constexpr int NWORKERS = 3;
 enum { LAT_NONE = 0u, LAT_LINEAR = 1u, LAT_DIRECT = 2u };	// how the workers get at the samples
@@ -925,29 +926,41 @@ struct Master {
 	bool done = false;
 	for ( uint32_t c0 = 0; c0 < zz.J && !done; c0 += qmax ) {
 	    const uint32_t Q = zz.J - c0 < qmax ? zz.J - c0 : qmax;
-	    // extent of this chunk's candidates
-	    uint32_t tlo = 0xFFFFFFFFu, thi = 0;
-	    for ( uint32_t i = 0; i < Q; i++ ) {
-		const uint32_t t = zz.at(c0 + i);
-		tlo = t < tlo ? t : tlo;
-		thi = t > thi ? t : thi;
-	    }
+	    // Extent of this chunk's candidates, in closed form: within the zig-zag
+	    // order the up-steps grow and the down-steps shrink with the index, so
+	    // the extremes are the LAST up / down step inside [c0, c0 + Q) -- or
+	    // the chunk's first candidate when it has none of that kind.
+	    const uint32_t iend = c0 + Q - 1u;
+	    const uint32_t lu = iend > 2u * zz.D ? iend : ( ( iend & 1u ) ? iend : iend - 1u );
+	    const uint32_t ld = ( iend < 2u * zz.D ? iend : 2u * zz.D ) & ~1u;
+	    const bool has_up = lu >= ( c0 > 1u ? c0 : 1u ) && lu <= iend && iend >= 1u;
+	    const bool has_down = ld >= 2u && ld >= c0;
+	    const uint32_t thi = has_up ? zz.at(lu) : zz.at(c0);
+	    const uint32_t tlo = has_down ? zz.at(ld) : zz.at(c0);
 	    if ( lane < Q )
 		lds->c_pos[lane] = base + zz.at(c0 + lane);
 	    lat_n = 0;			// the SCAN's scores overwrite the lattice frames'
 	    evaluate(Q, kind, base + tlo, base + thi + cfg.last_reach);
-	    for ( uint32_t i = 0; i < Q; i++ ) {	// fsk.c:492-501
-		const float c = lds->c_conf[i];
+	    // fsk.c:492-501 over the chunk: one LDS read, then the reference's
+	    // selection in scan order on lane values (strict >, first wins ties,
+	    // stop at the limit); the winner's other fields are fetched once
+	    const float cl = lane < Q ? lds->c_conf[lane] : 0.0f;
+	    uint32_t win = ~0u;
+	    for ( uint32_t i = 0; i < Q; i++ ) {
+		const float c = lane_bcast(cl, i);
 		if ( r.conf < c ) {
 		    r.conf = c;
-		    r.ampl = lds->c_ampl[i];
-		    r.bits = lds->c_bits[i];
-		    r.start = zz.at(c0 + i);
+		    win = i;
 		    if ( r.conf >= limit ) {
 			done = true;
 			break;
 		    }
 		}
+	    }
+	    if ( win != ~0u ) {
+		r.ampl = lds->c_ampl[win];
+		r.bits = lds->c_bits[win];
+		r.start = zz.at(c0 + win);
 	    }
 	}
 	return r;
