@@ -1617,7 +1617,13 @@ __device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const 
 	float *lane_base = region + ( lane << 2 );
 	const uint32_t nvec_lane = nvec > lane ? nvec - lane : 0u;	// vector i stored iff 64 i < nvec_lane
 	const uint32_t elast = lo + kRoundFloats;
-	if ( elast <= N && elast >= lo ) {
+	if ( elast <= N && elast >= lo && region_floats >= kRoundFloats ) {
+	    // the region holds a whole round of vectors: store them all, needed or
+	    // not (no per-vector predicates: ten plain ds_write_b128)
+#pragma unroll
+	    for ( int i = 0; i < STAGE_VEC; i++ )
+		*reinterpret_cast<float4 *>(lane_base + i * 256) = pbuf[i];
+	} else if ( elast <= N && elast >= lo ) {
 #pragma unroll
 	    for ( int i = 0; i < STAGE_VEC; i++ )
 		if ( (uint32_t)( i * 64 ) < nvec_lane )
