@@ -462,3 +462,48 @@ def synthesize_batch(ctx, cfg, words, nwords=None, lut=4096, amplitude=1.0, lead
     if rc != 0:
         raise RuntimeError("mifsk_tx_synthesize_batch -> %d" % rc)
     return out, lens
+
+
+def demod_batch_host(ctx, cfg, samples, nsamples=None, frames_cap=None, episodes_cap=8):
+    """mifsk_demod_batch_host: the whole batch from HOST memory in one call (copies
+    in, runs the receive loop on the device, copies out, synchronises).  samples is a
+    float32 numpy array [nstreams, stride]; returns a dict of numpy arrays."""
+    lib = _lib.load()
+    samples = np.ascontiguousarray(samples, dtype=np.float32)
+    nstreams, stride = samples.shape
+    if frames_cap is None:
+        frames_cap = max_frames(cfg, stride)
+    res = {
+        "bytes": np.zeros((nstreams, frames_cap), np.uint8),
+        "nbytes": np.zeros(nstreams, np.uint32),
+        "bits": np.zeros((nstreams, frames_cap), np.uint64),
+        "frames": np.zeros((nstreams, frames_cap), FRAME_DTYPE),
+        "nframes": np.zeros(nstreams, np.uint32),
+        "episodes": np.zeros((nstreams, episodes_cap), EPISODE_DTYPE),
+        "nepisodes": np.zeros(nstreams, np.uint32),
+        "status": np.zeros(nstreams, np.uint32),
+        "carrier_band": np.full(nstreams, -1, np.int32),
+    }
+    io = _lib.DemodIO()
+    io.d_samples = samples.ctypes.data
+    io.stream_stride = stride
+    if nsamples is not None:
+        nsamples = np.ascontiguousarray(nsamples, dtype=np.uint32)
+        io.d_nsamples = nsamples.ctypes.data
+    io.nsamples = stride
+    io.nstreams = nstreams
+    io.d_bytes = res["bytes"].ctypes.data
+    io.d_nbytes = res["nbytes"].ctypes.data
+    io.d_bits = res["bits"].ctypes.data
+    io.d_frames = res["frames"].ctypes.data
+    io.d_nframes = res["nframes"].ctypes.data
+    io.frames_cap = frames_cap
+    io.d_episodes = res["episodes"].ctypes.data
+    io.d_nepisodes = res["nepisodes"].ctypes.data
+    io.episodes_cap = episodes_cap
+    io.d_status = res["status"].ctypes.data
+    io.d_carrier_band = res["carrier_band"].ctypes.data
+    rc = lib.mifsk_demod_batch_host(ctx.handle, C.byref(cfg), C.byref(io))
+    if rc != 0:
+        raise RuntimeError("mifsk_demod_batch_host failed: %d" % rc)
+    return res

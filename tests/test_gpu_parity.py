@@ -246,6 +246,35 @@ def test_auto_carrier_batch_with_different_tones_per_stream(gpu, mode, tones):
     assert found == len(tones)
 
 
+@pytest.mark.parametrize("mode,kw", [("1200", {}), ("same", {}),
+                                     ("300", dict(auto_carrier_threshold=0.001))])
+def test_demod_batch_host_entry_point(gpu, mode, kw):
+    """mifsk_demod_batch_host: host pointers in, host results out (ragged rows whose
+    stride is not a multiple of 4, --auto-carrier bands included)."""
+    M, torch, ctx = gpu
+    cfg = M.rx_config(mode, **kw)
+    ocfg = O.oracle_config(mode, **kw)
+    rng = np.random.default_rng(21)
+    streams = []
+    for i in range(7):
+        words = rng.integers(32, 127, size=20 + 3 * i, dtype=np.uint8)
+        streams.append(M.synthesize(cfg, words, leading_silence=int(rng.integers(0, 500)),
+                                    amplitude=float(rng.uniform(0.3, 1.0))))
+    streams.append(np.zeros(0, np.float32))
+    stride = max(len(s) for s in streams) + 1          # odd on purpose
+    host = np.zeros((len(streams), stride), np.float32)
+    lens = np.zeros(len(streams), np.uint32)
+    for i, s in enumerate(streams):
+        host[i, :len(s)] = s
+        lens[i] = len(s)
+    res = M.demod_batch_host(ctx, cfg, host, lens, episodes_cap=16)
+    for i, s in enumerate(streams):
+        ref = O.oracle_rx_stream(ocfg, s, ring_mode=False)
+        assert_stream_equal(res, i, ref, mode)
+        if kw:
+            assert int(res["carrier_band"][i]) == ref["carrier_band"]
+
+
 def test_output_capacity_overflow_is_flagged(gpu):
     M, torch, ctx = gpu
     cfg = M.rx_config("1200")
