@@ -130,9 +130,11 @@ int  mifsk_rx_config_init( mifsk_rx_config *cfg, const mifsk_modem_args *args );
 
 /* upper bound on frames one stream of nsamples can yield */
 size_t mifsk_max_frames( const mifsk_rx_config *cfg, size_t nsamples );
-/* zero-filled floats the caller must keep readable after each stream's last
- * sample (reads past the end of a stream see zeros; the reference reads stale
- * ring-buffer memory there -- DESIGN.md "past-the-end reads") */
+/* How far past a stream's last sample a search may logically look (last
+ * candidate position + last bit window, fsk.c:204-206,480).  Informational:
+ * those samples read as 0.0 whatever the memory holds -- the kernels never
+ * touch a row beyond nsamples[s], so no padding is required (the reference
+ * reads stale ring-buffer memory there -- DESIGN.md "past-the-end reads"). */
 size_t mifsk_stream_padding( const mifsk_rx_config *cfg );
 
 /* ---- device context --------------------------------------------------- */

@@ -85,3 +85,13 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_between_bindings():
     assert C.sizeof(_lib.RxConfig) == C.sizeof(O.RxConfig)
     assert C.sizeof(_lib.ModemArgs) == C.sizeof(O.ModemArgs)
+
+
+def test_stream_padding_is_the_search_reach():
+    """mifsk_stream_padding = last candidate position + last bit window, rounded to 4."""
+    lib = M._lib.load()
+    for mode in ("1200", "300", "rtty", "same", "12000"):
+        cfg = M.rx_config(mode)
+        reach = max(cfg.try_max[0], cfg.try_max[1])
+        last = cfg.bit_offset[cfg.expect_n_bits - 1] + cfg.bit_nsamples
+        assert lib.mifsk_stream_padding(C.byref(cfg)) == (reach + last + 3) & ~3
