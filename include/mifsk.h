@@ -132,9 +132,11 @@ int  mifsk_rx_config_init( mifsk_rx_config *cfg, const mifsk_modem_args *args );
 size_t mifsk_max_frames( const mifsk_rx_config *cfg, size_t nsamples );
 /* How far past a stream's last sample a search may logically look (last
  * candidate position + last bit window, fsk.c:204-206,480).  Informational:
- * those samples read as 0.0 whatever the memory holds -- the kernels never
- * touch a row beyond nsamples[s], so no padding is required (the reference
- * reads stale ring-buffer memory there -- DESIGN.md "past-the-end reads"). */
+ * those samples read as 0.0 whatever the memory holds, so no padding is
+ * required.  (The kernels may load -- and ignore -- floats between a row's
+ * nsamples[s] and the end of the batch's rows, never anything past the last
+ * row's own samples.  The reference reads stale ring-buffer memory there --
+ * DESIGN.md "past-the-end reads".) */
 size_t mifsk_stream_padding( const mifsk_rx_config *cfg );
 
 /* ---- device context --------------------------------------------------- */
