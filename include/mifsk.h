@@ -134,9 +134,9 @@ size_t mifsk_max_frames( const mifsk_rx_config *cfg, size_t nsamples );
  * candidate position + last bit window, fsk.c:204-206,480).  Informational:
  * those samples read as 0.0 whatever the memory holds, so no padding is
  * required.  (The kernels may load -- and ignore -- floats between a row's
- * nsamples[s] and the end of the batch's rows, never anything past the last
- * row's own samples.  The reference reads stale ring-buffer memory there --
- * DESIGN.md "past-the-end reads".) */
+ * nsamples[s] and the end of the batch: all nstreams * stream_stride floats
+ * must be readable, nothing beyond them is touched.  The reference reads
+ * stale ring-buffer memory there -- DESIGN.md "past-the-end reads".) */
 size_t mifsk_stream_padding( const mifsk_rx_config *cfg );
 
 /* ---- device context --------------------------------------------------- */
