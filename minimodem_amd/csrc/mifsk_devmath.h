@@ -10,11 +10,33 @@ namespace mifsk {
 // is a pair of floats; hypotf in glibc 2.35 is exactly
 // (float)sqrt((double)re*re + (double)im*im) (verified exhaustively on the
 // host, tests/test_host_math.py); f64 sqrt on gfx950 is correctly rounded.
+// sqrt() of a double that is 0 or at least 2^-298 (a sum of squares of floats):
+// the compiler's own correctly rounded sequence for gfx950 -- v_rsq_f64, one
+// coupled Newton step on (g ~ sqrt s, h ~ 1/(2 sqrt s)), two residual
+// corrections -- without the exponent pre-scaling it wraps around it for
+// arguments below 2^-767, which cannot occur here (5 of its 18 instructions).
+// Same instructions, same order: identical results (every parity test compares
+// magnitudes bit for bit).
+__device__ __forceinline__ double sqrt_sumsq( double s )
+{
+    const double r = __builtin_amdgcn_rsq(s);
+    double g = s * r;
+    double h = r * 0.5;
+    const double e = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, e, g);
+    double d = __builtin_fma(-g, g, s);
+    h = __builtin_fma(h, e, h);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, s);
+    g = __builtin_fma(d, h, g);
+    return ( s == 0.0 || s == __builtin_inf() ) ? s : g;
+}
+
 __device__ __forceinline__ float band_mag( double re, double im, float scalar )
 {
     const float fr = (float)re, fi = (float)im;
     const double s = (double)fr * (double)fr + (double)fi * (double)fi;
-    return (float)sqrt(s) * scalar;
+    return (float)sqrt_sumsq(s) * scalar;
 }
 
 } // namespace mifsk
