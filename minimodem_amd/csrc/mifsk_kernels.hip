@@ -848,6 +848,16 @@ struct Master {
 	cyc_conf += MIFSK_CLOCK() - t_c;
     }
 
+    // Whatever the failing frame's fate, the batch in flight sits on a lattice the
+    // cursor is about to leave: tell the workers to drop it now (their issue slots
+    // are better spent by the other workgroups' waves).
+    __device__ __forceinline__ void give_up()
+    {
+	if ( inflight && lane == 0 )	// command number seq - 1 is the batch in flight
+	    *(volatile uint32_t *)&lds->abort = seq;
+	inflight = false;
+    }
+
     // SCAN: evaluate candidates c_pos[0..nq) (already in LDS) spanning [lo, hi)
     __device__ __forceinline__ void evaluate( uint32_t nq, uint32_t kind, uint32_t lo, uint32_t hi )
     {
@@ -1189,6 +1199,8 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 		    atot = lane_bcast(my_sa, n);
 		}
 		ctx.run += n;
+		if ( bad != 0ULL )		// (<=> n < K)
+		    ctx.give_up();
 		if ( n < K ) {			// the lattice broke here: remember how long it held
 		    ctx.spec = ctx.run < ctx.spec_floor ? ctx.spec_floor
 			     : ( ctx.run < ctx.lat_batch ? ctx.run : ctx.lat_batch );
@@ -1820,11 +1832,14 @@ __device__ __forceinline__ void worker_main( const DevCfg *__restrict__ cfgp,
 		// rounds of lat_frames frames (what the regions hold)
 		const uint32_t total = cmd->frames;
 		uint32_t win_base = 0;
-		// (no give-up poll here: a LINEAR batch retires within about a
-		// microsecond of the master asking -- measured)
-		for ( uint32_t done = 0; done < total; done += lat_frames, win_base += wins_per_round )
+		for ( uint32_t done = 0; done < total; done += lat_frames, win_base += wins_per_round ) {
+		    // given up by the master (the lattice broke in the batch before):
+		    // the issue slots are better spent by the other workgroups' waves
+		    if ( *(volatile uint32_t *)&lds->abort == seq + 1u )
+			break;
 		    worker_lattice_linear(cfg, tw, lds, cmd, x, N, region_floats, lat_frames,
 					  wkr, done, win_base, rel_lane, safe_limit, pbuf, pref_org4, wcyc);
+		}
 	    } else {
 		const uint32_t total = cmd->frames;
 		uint32_t win_base = 0;
