@@ -631,6 +631,8 @@ __device__ __forceinline__ void par_correlate( const DevCfg &cfg, const double *
     const uint32_t nwin = nq * n_bits;
     for ( uint32_t w0 = 0; w0 < nwin; w0 += BLOCK ) {
 	const uint32_t w = w0 + threadIdx.x;
+	if ( w0 + ( threadIdx.x & ~63u ) >= nwin )
+	    continue;			// nothing for this wave in this pass (a refinement has ~90 windows)
 	const bool active = w < nwin;
 	const uint32_t q = active ? udiv_magic(w, n_bits, cfg.nbits_magic) : 0;
 	const uint32_t k = active ? w - q * n_bits : 0;
@@ -1199,7 +1201,10 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 		    atot = lane_bcast(my_sa, n);
 		}
 		ctx.run += n;
-		if ( bad != 0ULL )		// (<=> n < K)
+		// (bad != 0 <=> n < K.)  With a search step of one sample a "refine"
+		// is a flag and no search (minimodem.c:1357): the cursor stays on the
+		// lattice and the batch in flight stays good -- 12000 baud lives there
+		if ( bad != 0ULL && cfg.try_step[1] > 1u )
 		    ctx.give_up();
 		if ( n < K ) {			// the lattice broke here: remember how long it held
 		    ctx.spec = ctx.run < ctx.spec_floor ? ctx.spec_floor
