@@ -203,21 +203,11 @@ def main():
         if world > 1:
             pending[b] = gather_async(bufs[b])
 
-    gathered = {}
+    gatherer = M.ByteGatherer(dist, rank, world)
 
     def gather_async(buf):
         """decoded bytes -> rank 0, grouped send/recv (each peer uses its own xGMI link)"""
-        if rank == 0:
-            if "rx" not in gathered:
-                gathered["rx"] = [(torch.empty_like(buf["bytes"]), torch.empty_like(buf["nbytes"]))
-                                  for _ in range(world - 1)]
-            ops = []
-            for r in range(1, world):
-                ops.append(dist.P2POp(dist.irecv, gathered["rx"][r - 1][0], r))
-                ops.append(dist.P2POp(dist.irecv, gathered["rx"][r - 1][1], r))
-        else:
-            ops = [dist.P2POp(dist.isend, buf["bytes"], 0), dist.P2POp(dist.isend, buf["nbytes"], 0)]
-        return dist.batch_isend_irecv(ops)
+        return gatherer.start(buf["bytes"], buf["nbytes"])
 
     def drain():
         for b in (0, 1):

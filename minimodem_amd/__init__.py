@@ -325,6 +325,39 @@ def gather_bytes(local_bytes, local_nbytes, dst=0, group=None):
     return None, None
 
 
+class ByteGatherer:
+    """Overlapped gather of decoded bytes to rank 0 for a pipelined caller
+    (bench.py): start(bytes, nbytes) posts one grouped send/recv -- every peer
+    sends on its own link to the root (RCCL over xGMI on GPUs, gloo in the CPU
+    tests) -- and returns the work handles; the caller waits on them before it
+    reuses the buffers it passed.  On the root, received(r) is the latest
+    (bytes, nbytes) of peer r >= 1 once its handles have been waited on."""
+
+    def __init__(self, dist, rank, world):
+        self.dist, self.rank, self.world = dist, rank, world
+        self._rx = None
+
+    def start(self, local_bytes, local_nbytes):
+        dist = self.dist
+        if self.world == 1:
+            return []
+        if self.rank == 0:
+            if self._rx is None:
+                torch = _torch()
+                self._rx = [(torch.empty_like(local_bytes), torch.empty_like(local_nbytes))
+                            for _ in range(self.world - 1)]
+            ops = []
+            for r in range(1, self.world):
+                ops.append(dist.P2POp(dist.irecv, self._rx[r - 1][0], r))
+                ops.append(dist.P2POp(dist.irecv, self._rx[r - 1][1], r))
+        else:
+            ops = [dist.P2POp(dist.isend, local_bytes, 0), dist.P2POp(dist.isend, local_nbytes, 0)]
+        return dist.batch_isend_irecv(ops)
+
+    def received(self, r):
+        return self._rx[r - 1]
+
+
 DECODERS = {"ascii8": 0, "baudot": 1, "binary": 2, "callerid": 3, "uic-ground": 4, "uic-train": 5}
 TEXT_PRINT_FILTER = 1
 TEXT_QUIET = 2

@@ -1,6 +1,6 @@
 """The N>1 path on CPU: world_size-2 `gloo` processes exercise the stream
 sharding and the gather of decoded bytes to rank 0 (minimodem_amd.shard_range /
-gather_bytes -- the same code bench.py runs over RCCL on GPUs).  The demod
+gather_bytes, and ByteGatherer -- the class bench.py runs over RCCL on GPUs).  The demod
 kernel itself needs a GPU and is covered by the -m gpu tests; here each rank's
 "decoded bytes" come from the oracle so that the assembled result can be
 checked against a single-process decode of the whole batch."""
@@ -89,3 +89,55 @@ def test_shard_range_partitions_exactly():
                 assert a[1] == b[0]
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _pipelined_worker(rank, world, port, q):
+    """bench.py's N>1 step structure: double-buffered outputs, the gather of step i
+    overlapped with step i+1, waited on before its buffers are reused."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = M.ByteGatherer(dist, rank, world)
+        bufs = [(torch.zeros((3, 8), dtype=torch.uint8), torch.zeros(3, dtype=torch.int32))
+                for _ in range(2)]
+        pending = [None, None]
+        seen = []
+        for step in range(5):
+            b = step & 1
+            if pending[b] is not None:
+                for w in pending[b]:
+                    w.wait()
+                pending[b] = None
+            bufs[b][0].fill_(10 * rank + step)       # "decode" step into buffer b
+            bufs[b][1].fill_(step + 1)
+            pending[b] = g.start(*bufs[b])
+            if rank == 0:                             # (the root checks what the previous step brought)
+                for w in pending[b]:
+                    w.wait()
+                pending[b] = None
+                seen.append([(int(g.received(r)[0][0, 0]), int(g.received(r)[1][0]))
+                             for r in range(1, world)])
+        for b in (0, 1):
+            if pending[b] is not None:
+                for w in pending[b]:
+                    w.wait()
+        dist.barrier()
+        if rank == 0:
+            q.put(seen)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_gather_as_in_bench():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipelined_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    seen = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert seen == [[(10 + step, step + 1)] for step in range(5)]
