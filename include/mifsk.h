@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define MIFSK_MAX_FRAME_BITS	64	/* fsk.c:185-187,463 */
-#define MIFSK_ABI_VERSION	2
+#define MIFSK_ABI_VERSION	3
 
 /* which databits decoder main() would have selected (minimodem.c:549-553,
  * 675,820,856,866,892).  Decoding frame bits to text is O(1)/frame host work
@@ -199,7 +199,10 @@ typedef struct mifsk_episode {
     float	confidence_total;
     float	amplitude_total;
     uint32_t	end_reason;	/* 1: carrier lost, 2: end of stream        */
-    uint32_t	reserved;
+    uint32_t	b_mark;		/* the plan's mark band when the carrier was
+				   acquired ("### CARRIER ... @ f Hz" is
+				   b_mark * band_width; with --auto-carrier it
+				   can change from episode to episode)      */
 } mifsk_episode;
 
 #define MIFSK_STREAM_FRAMES_TRUNCATED	1u

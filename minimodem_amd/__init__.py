@@ -27,7 +27,7 @@ FRAME_DTYPE = np.dtype([("bits", "<u8"), ("start", "<u8"), ("confidence", "<f4")
 EPISODE_DTYPE = np.dtype([("carrier_nsamples", "<u8"), ("first_frame", "<u4"),
                           ("nframes", "<u4"), ("confidence_total", "<f4"),
                           ("amplitude_total", "<f4"), ("end_reason", "<u4"),
-                          ("reserved", "<u4")])
+                          ("b_mark", "<u4")])
 SEARCH_DTYPE = np.dtype([("sample_offset", "<u8"), ("navail", "<u4"), ("try_first", "<u4"),
                          ("try_max", "<u4"), ("try_step", "<u4"), ("search_limit", "<f4"),
                          ("use_sync_string", "<u4")])
@@ -109,6 +109,16 @@ def _stream_ptr(torch, stream):
     return C.c_void_p(stream.cuda_stream)
 
 
+def _check_nsamples(torch, nsamples, nstreams):
+    """Per-stream lengths cross the C ABI as a raw uint32 pointer: reject what the
+    kernels would silently misread (a CPU tensor, int64 lengths, a wrong shape)."""
+    if nsamples is None:
+        return
+    assert nsamples.is_cuda and nsamples.dtype in (torch.int32, torch.uint32), \
+        "nsamples must be a CUDA int32/uint32 tensor"
+    assert nsamples.dim() == 1 and nsamples.shape[0] == nstreams and nsamples.is_contiguous()
+
+
 def max_frames(cfg, nsamples):
     return int(_lib.load().mifsk_max_frames(C.byref(cfg), int(nsamples)))
 
@@ -128,6 +138,8 @@ def demod_batch(ctx, cfg, samples, nsamples=None, want=("bytes", "episodes"),
     assert samples.is_cuda and samples.dtype == torch.float32 and samples.dim() == 2
     assert samples.stride(1) == 1
     nstreams, width = samples.shape
+    _check_nsamples(torch, nsamples, nstreams)     # (the kernels clamp lengths to the row width)
+
     stride = samples.stride(0)
     n_uniform = int(width)
     if frames_cap is None:
@@ -396,14 +408,9 @@ def stream_text(cfg, bits, episodes, print_filter=False, quiet=False, b_mark=Non
     """What minimodem writes for one stream: (stdout bytes, stderr str) from the
     frame data bits (numpy uint64, loop order) and its episodes (EPISODE_DTYPE);
     host post-pass mifsk_stream_text (reference src/minimodem.c:253-291,1336-1461).
-    b_mark: the stream's autodetected mark band (--auto-carrier), which the
-    "### CARRIER ... @ f Hz" line is printed from."""
+    The "### CARRIER ... @ f Hz" line is printed from each episode's own b_mark
+    (`b_mark` is accepted for callers of the older signature and ignored)."""
     lib = _lib.load()
-    if b_mark is not None and int(b_mark) >= 0:
-        c2 = RxConfig()
-        C.memmove(C.byref(c2), C.byref(cfg), C.sizeof(RxConfig))
-        c2.b_mark = int(b_mark)
-        cfg = c2
     bits = np.ascontiguousarray(bits, dtype=np.uint64)
     episodes = np.ascontiguousarray(episodes, dtype=EPISODE_DTYPE)
     flags = (TEXT_PRINT_FILTER if print_filter else 0) | (TEXT_QUIET if quiet else 0)
@@ -437,6 +444,7 @@ def ingest_s16(ctx, pcm, nsamples=None, rxnoise=0.0, stride=None, stream=None):
     torch = _torch()
     assert pcm.is_cuda and pcm.dtype == torch.int16 and pcm.dim() == 2 and pcm.stride(1) == 1
     nstreams, width = pcm.shape
+    _check_nsamples(torch, nsamples, nstreams)
     if stride is None:
         stride = (width + 3) & ~3
     out = torch.empty((nstreams, stride), dtype=torch.float32, device=pcm.device)
@@ -454,6 +462,7 @@ def ingest_rxnoise(ctx, samples, rxnoise, nsamples=None, stream=None):
     """The --Xrxnoise term applied in place to float32 CUDA samples [nstreams, stride]."""
     torch = _torch()
     assert samples.is_cuda and samples.dtype == torch.float32 and samples.dim() == 2
+    _check_nsamples(torch, nsamples, samples.shape[0])
     rc = _lib.load().mifsk_ingest_rxnoise_f32(
         ctx.handle, C.c_void_p(samples.data_ptr()), samples.stride(0),
         C.c_void_p(nsamples.data_ptr()) if nsamples is not None else None, int(samples.shape[1]),

@@ -50,6 +50,7 @@ void fill_devcfg( DevCfg &d, const mifsk_rx_config &c )
     d.do_rx_sync = c.do_rx_sync ? 1u : 0u;
     d.rx_one = c.rx_one ? 1u : 0u;
     d.sync_byte = c.sync_byte;
+    d.b_mark = c.b_mark;
     // odd row pitch => lanes one bit apart never share an LDS bank
     d.skew = ( c.bit_nsamples & 1u ) ? 0u : 1u;
     d.div_magic = c.bit_nsamples > 1 ? (uint32_t)( 0x100000000ULL / c.bit_nsamples ) : 0xFFFFFFFFu;

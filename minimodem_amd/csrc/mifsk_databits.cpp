@@ -260,10 +260,12 @@ struct Sink {
 };
 
 // "### CARRIER 1200 @ 1200.0 Hz ###\n" -- minimodem.c:1336-1348
-std::string carrier_line( const mifsk_rx_config *cfg )
+// (fskp->b_mark at the time of the acquisition: the episode carries it, because
+// --auto-carrier can move the tones between episodes, minimodem.c:1297,1219)
+std::string carrier_line( const mifsk_rx_config *cfg, const mifsk_episode &e )
 {
     char b[128];
-    const double hz = (double)( (float)cfg->b_mark * cfg->band_width );
+    const double hz = (double)( (float)e.b_mark * cfg->band_width );
     if ( cfg->data_rate >= 100 )
 	snprintf(b, sizeof b, "### CARRIER %u @ %.1f Hz ###\n",
 		 (unsigned)( cfg->data_rate + 0.5f ), hz);
@@ -323,7 +325,7 @@ extern "C" int mifsk_stream_text( const mifsk_rx_config *cfg,
 	    if ( e > 0 && !quiet )
 		se.add(nocarrier_line(cfg, episodes[e - 1]));
 	    if ( !quiet )
-		se.add(carrier_line(cfg));
+		se.add(carrier_line(cfg, episodes[e]));
 	    mifsk_databits_reset(&dec);					// minimodem.c:1351
 	    e++;
 	}
@@ -347,7 +349,7 @@ extern "C" int mifsk_stream_text( const mifsk_rx_config *cfg,
 	// was too short to reach: truncated outputs)
 	for ( uint32_t k = e ? e - 1 : 0; k < nepisodes; k++ ) {
 	    if ( k >= e )
-		se.add(carrier_line(cfg));
+		se.add(carrier_line(cfg, episodes[k]));
 	    se.add(nocarrier_line(cfg, episodes[k]));
 	}
     }

@@ -40,6 +40,7 @@ struct DevCfg {
     // frame IS the first window of the next, and a round of F frames has only
     // F (n_bits - 1) + 1 distinct windows
     uint32_t	lat_grid;
+    uint32_t	b_mark;			// the plan's mark band (episodes report it)
     uint32_t	bit_offset[MIFSK_MAX_FRAME_BITS];	// fsk.c:204
     // expect strings as bit masks, [0]=data [1]=sync: bit k of req_mask is set
     // when bit k of the frame is required ('0'/'1'), req_val holds its value

@@ -1,0 +1,646 @@
+// mifsk_devlib.h -- device-side building blocks shared by the receive-loop
+// kernels (mifsk_kernels.hip: one workgroup per stream, master + worker waves;
+// mifsk_wave.hip: one wavefront per stream).  Everything here is arithmetic or
+// a memory idiom with a fixed operation order: both kernels produce the
+// oracle's results bit for bit because they share these sequences.
+// gfx950 only; included by .hip files only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+
+#include "mifsk_device.h"
+#include "mifsk_devmath.h"
+
+namespace mifsk {
+
+constexpr int BLOCK = 256;	// threads per stream workgroup (4 waves)
+constexpr int P_CAP = 64;	// candidate positions per batch (= one wave of lanes)
+constexpr int W_CAP = 448;	// bit windows per batch (LDS scratch)
+
+// ---------------------------------------------------------------------------
+// arithmetic shared by every kernel
+// ---------------------------------------------------------------------------
+
+struct FrameOut {
+    float	conf;
+    float	ampl;
+    uint64_t	bits;
+};
+
+// fsk_frame_analyze after the per-bit magnitudes are known (fsk.c:199-212,
+// 271-342, 439-441).  `mags[k]` = (mark, space) magnitude of bit k.  One lane
+// runs this for one candidate position; every operation is f32, in the
+// reference's order (contraction is disabled for this file).  The magnitudes
+// are fetched from LDS eight at a time so that the loads (and, in the second
+// pass, the independent divisions) overlap; the running sums stay sequential.
+constexpr int CCH = 5;
+
+__device__ __forceinline__ FrameOut
+frame_confidence( const float2 *mags, uint64_t req_mask, uint64_t req_val, uint32_t n_bits )
+{
+    FrameOut out;
+    out.conf = 0.0f;
+    out.ampl = 0.0f;
+    out.bits = 0;
+
+    uint64_t bits = 0;
+    float total_sig = 0.0f, total_noise = 0.0f;
+    float mark_sig = 0.0f, space_sig = 0.0f;
+    uint32_t n_mark = 0;
+    const uint32_t last = n_bits - 1u;
+    for ( uint32_t k0 = 0; k0 < n_bits; k0 += CCH ) {
+	float2 m[CCH];
+#pragma unroll
+	for ( int j = 0; j < CCH; j++ )
+	    m[j] = mags[k0 + j < last ? k0 + j : last];
+#pragma unroll
+	for ( int j = 0; j < CCH; j++ ) {
+	    if ( k0 + j < n_bits ) {
+		const bool one = m[j].x > m[j].y;		// fsk.c:161 (strict)
+		const float sig = one ? m[j].x : m[j].y;
+		const float noise = one ? m[j].y : m[j].x;
+		bits |= (uint64_t)( one ? 1u : 0u ) << ( k0 + j );
+		total_sig += sig;				// fsk.c:278
+		if ( noise > FLT_EPSILON )			// fsk.c:279
+		    total_noise += noise;
+		if ( one ) {
+		    mark_sig += sig;
+		    n_mark++;
+		} else {
+		    space_sig += sig;
+		}
+	    }
+	}
+    }
+    // a required bit that came out wrong rejects the frame with confidence 0
+    // and bits/ampl untouched (fsk.c:211-212,486-487)
+    if ( ( bits ^ req_val ) & req_mask )
+	return out;
+    const uint32_t n_space = n_bits - n_mark;
+
+    const float snr = total_sig / total_noise;		// fsk.c:292
+    const float avg_sig = total_sig / (float)(int)n_bits;	// fsk.c:295 (int n_bits)
+    if ( n_mark )
+	mark_sig /= (float)n_mark;			// fsk.c:298-301
+    if ( n_space )
+	space_sig /= (float)n_space;
+
+    float divergence = 0.0f;				// fsk.c:305-313
+    for ( uint32_t k0 = 0; k0 < n_bits; k0 += CCH ) {
+	float term[CCH];
+#pragma unroll
+	for ( int j = 0; j < CCH; j++ ) {
+	    const float2 m = mags[k0 + j < last ? k0 + j : last];
+	    const bool one = m.x > m.y;
+	    const float sig = one ? m.x : m.y;
+	    const float cls = one ? mark_sig : space_sig;
+	    term[j] = fabsf(sig - cls) / cls;
+	}
+#pragma unroll
+	for ( int j = 0; j < CCH; j++ )
+	    if ( k0 + j < n_bits )
+		divergence += term[j];
+    }
+    divergence *= 2.0f;
+    divergence /= (float)(int)n_bits;
+
+    out.conf = snr * (1.0f - divergence);		// fsk.c:336
+    out.ampl = avg_sig;					// fsk.c:342
+    out.bits = bits;					// fsk.c:439-441
+    return out;
+}
+
+// The same for a frame length known at compile time: every magnitude is loaded
+// once (all loads in flight together), the per-bit signal levels stay in
+// registers for the divergence pass, nothing is computed for padding slots.
+// Operation for operation the sequence above.
+template <int NB>
+__device__ __forceinline__ FrameOut
+frame_confidence_fixed( const float2 *mags, uint64_t req_mask, uint64_t req_val )
+{
+    FrameOut out;
+    out.conf = 0.0f;
+    out.ampl = 0.0f;
+    out.bits = 0;
+
+    float2 m[NB];
+#pragma unroll
+    for ( int k = 0; k < NB; k++ )
+	m[k] = mags[k];
+    uint32_t bits = 0;					// NB <= 32 here
+    float sig[NB];
+    float total_sig = 0.0f, total_noise = 0.0f;
+    float mark_sig = 0.0f, space_sig = 0.0f;
+    uint32_t n_mark = 0;
+#pragma unroll
+    for ( int k = 0; k < NB; k++ ) {
+	const bool one = m[k].x > m[k].y;		// fsk.c:161 (strict)
+	sig[k] = one ? m[k].x : m[k].y;
+	const float noise = one ? m[k].y : m[k].x;
+	bits |= ( one ? 1u : 0u ) << k;
+	total_sig += sig[k];				// fsk.c:278
+	if ( noise > FLT_EPSILON )			// fsk.c:279
+	    total_noise += noise;
+	if ( one ) {
+	    mark_sig += sig[k];
+	    n_mark++;
+	} else {
+	    space_sig += sig[k];
+	}
+    }
+    if ( ( (uint64_t)bits ^ req_val ) & req_mask )	// fsk.c:211-212,486-487
+	return out;
+    const uint32_t n_space = (uint32_t)NB - n_mark;
+
+    const float snr = total_sig / total_noise;		// fsk.c:292
+    const float avg_sig = total_sig / (float)NB;	// fsk.c:295
+    if ( n_mark )
+	mark_sig /= (float)n_mark;			// fsk.c:298-301
+    if ( n_space )
+	space_sig /= (float)n_space;
+
+    float term[NB];					// fsk.c:305-313
+#pragma unroll
+    for ( int k = 0; k < NB; k++ ) {
+	const float cls = ( bits >> k ) & 1u ? mark_sig : space_sig;
+	term[k] = fabsf(sig[k] - cls) / cls;
+    }
+    float divergence = 0.0f;
+#pragma unroll
+    for ( int k = 0; k < NB; k++ )
+	divergence += term[k];
+    divergence *= 2.0f;
+    divergence /= (float)NB;
+
+    out.conf = snr * (1.0f - divergence);		// fsk.c:336
+    out.ampl = avg_sig;					// fsk.c:342
+    out.bits = bits;					// fsk.c:439-441
+    return out;
+}
+
+// frame lengths with a specialised confidence pass: start + 8 data + stop with
+// the previous stop bit (11), the 7-bit variant (10); everything else is generic
+__device__ __forceinline__ FrameOut
+frame_confidence_any( const float2 *mags, uint64_t req_mask, uint64_t req_val, uint32_t n_bits )
+{
+    if ( n_bits == 11u )
+	return frame_confidence_fixed<11>(mags, req_mask, req_val);
+    if ( n_bits == 10u )
+	return frame_confidence_fixed<10>(mags, req_mask, req_val);
+    return frame_confidence(mags, req_mask, req_val, n_bits);
+}
+
+// The reference's zig-zag scan order (fsk.c:477-484): first, first+s, first-s,
+// first+2s, first-2s, ...; an up-step reaching try_max ends the scan, a
+// down-step below 0 is skipped.  Closed form: U up-positions (u = 0..U-1),
+// D valid down-positions (u = 1..D), J = U + D candidates in total.
+struct ZigZag {
+    uint32_t first, step, U, D, J;
+    __device__ __forceinline__ ZigZag( uint32_t f, uint32_t mx, uint32_t s )
+    {
+	first = f;
+	step = s;
+	if ( (int)f >= (int)mx || s == 0 ) {
+	    U = D = J = 0;
+	} else {
+	    U = ( mx - f - 1 ) / s + 1;
+	    const uint32_t dmax = f / s;
+	    D = U - 1 < dmax ? U - 1 : dmax;
+	    J = U + D;
+	}
+    }
+    // i-th candidate (0-based, scan order)
+    __device__ __forceinline__ uint32_t at( uint32_t i ) const
+    {
+	if ( i == 0 )
+	    return first;
+	if ( i <= 2 * D ) {
+	    const uint32_t u = ( i + 1 ) >> 1;
+	    return ( i & 1u ) ? first + u * step : first - u * step;
+	}
+	return first + ( i - D ) * step;
+    }
+};
+
+constexpr int XCH = 8;		// samples per register chunk in the correlator
+constexpr int STAGE_VEC = 10;	// float4 per thread per staging round
+
+// rel / bit_nsamples without a hardware divide: magic = floor(2^32 / B)
+// under-estimates the quotient by at most one
+__device__ __forceinline__ void divmod_bit( const DevCfg &cfg, uint32_t rel, uint32_t &q, uint32_t &r )
+{
+    q = __umulhi(rel, cfg.div_magic);
+    r = rel - q * cfg.bit_nsamples;
+    if ( r >= cfg.bit_nsamples ) {
+	q++;
+	r -= cfg.bit_nsamples;
+    }
+}
+
+// x / d for a divisor whose magic = floor(2^32 / d) was computed on the host
+__device__ __forceinline__ uint32_t udiv_magic( uint32_t x, uint32_t d, uint32_t magic )
+{
+    uint32_t q = __umulhi(x, magic);
+    if ( x - q * d >= d )
+	q++;
+    return q;
+}
+
+// One aligned float4 of the stream at sample index a (a % 4 == 0), RAW: the
+// address is clamped into the row and nothing is done with the data, so that a
+// run of these loads is issued back to back and stays in flight together (any
+// branch or select on the loaded value makes the compiler drain vmcnt per
+// load).  Rows are padded to whole float4s (stream_stride % 4 == 0 and
+// N <= stream_stride), so the access is always inside the row.
+__device__ __forceinline__ float4 load4_raw( const float *__restrict__ x, uint32_t a, uint32_t N )
+{
+    const uint32_t aa = a < N ? a : 0u;
+    return *reinterpret_cast<const float4 *>(x + aa);	// 16 B per lane, coalesced
+}
+
+// ... and the masking that goes with it, applied when the data is consumed:
+// samples at or beyond N read as 0.0
+__device__ __forceinline__ float4 mask4( float4 s, uint32_t a, uint32_t N )
+{
+    s.x = a < N ? s.x : 0.0f;
+    s.y = ( a < N && a + 1 < N ) ? s.y : 0.0f;
+    s.z = ( a < N && a + 2 < N ) ? s.z : 0.0f;
+    s.w = ( a < N && a + 3 < N ) ? s.w : 0.0f;
+    return s;
+}
+
+// Write the float4 loaded from stream index a = org4 + first into a skewed slab
+// whose row 0 starts `head` samples after org4 (`first` = offset from org4).
+// The LDS word of slab-relative sample rel is rel + (rel / B) * skew: rows of
+// one bit length with `skew` pad words in between, so lanes whose windows start
+// a whole number of bits apart read different banks.  Samples at or beyond N
+// are written as 0.0; samples before row 0 or past `cap` are dropped.
+__device__ __forceinline__ void store4_skewed( const DevCfg &cfg, float *slab, uint32_t cap,
+	uint32_t first, uint32_t head, float4 s, uint32_t a, uint32_t N )
+{
+    const uint32_t B = cfg.bit_nsamples, skew = cfg.skew;
+    const uint32_t rel0 = first >= head ? first - head : 0u;
+    uint32_t q, r;
+    divmod_bit(cfg, rel0, q, r);
+    const uint32_t idx0 = rel0 + q * skew;
+    if ( first >= head && rel0 + 3 < cap && a + 3 < N && a + 3 >= a && B >= 4 ) {
+	// common case: four in-range samples, at most one row boundary inside
+	float *d = slab + idx0;
+	d[0] = s.x;
+	d[1 + ( r + 1 >= B ? skew : 0u )] = s.y;
+	d[2 + ( r + 2 >= B ? skew : 0u )] = s.z;
+	d[3 + ( r + 3 >= B ? skew : 0u )] = s.w;
+	return;
+    }
+    s = mask4(s, a, N);
+    const float e[4] = { s.x, s.y, s.z, s.w };
+    uint32_t idx = idx0;
+#pragma unroll
+    for ( int j = 0; j < 4; j++ ) {
+	const uint32_t rel = first + j - head;		// meaningful when first + j >= head
+	if ( first + j >= head && rel < cap ) {
+	    slab[idx] = e[j];
+	    idx++;
+	    if ( ++r == B ) {
+		r = 0;
+		idx += skew;
+	    }
+	}
+    }
+}
+
+// Twiddles of XCH = 8 consecutive samples (8 x 4 doubles = 64 SGPRs), fetched
+// through the scalar cache with all four loads in flight at once.  Inline asm
+// because the register allocator, left to itself in this large kernel, issues
+// them one at a time (load 16 SGPRs, wait, 8 FMAs, ...), which exposes the
+// scalar-memory latency four times per chunk.  The caller must execute
+// twiddle_wait() before touching the values.
+typedef double tw8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void twiddle_fetch( const double *t, tw8 &a, tw8 &b, tw8 &c, tw8 &d )
+{
+    asm volatile("s_load_dwordx16 %0, %4, 0x0\n\t"
+		 "s_load_dwordx16 %1, %4, 0x40\n\t"
+		 "s_load_dwordx16 %2, %4, 0x80\n\t"
+		 "s_load_dwordx16 %3, %4, 0xc0"
+		 : "=&s"(a), "=&s"(b), "=&s"(c), "=&s"(d)
+		 : "s"(t)
+		 : "memory");
+}
+
+__device__ __forceinline__ void twiddle_wait()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+#define MIFSK_FMA4(X, T, I)					\
+    do {							\
+	const double xd_ = (double)(X);				\
+	mr = fma(xd_, (T)[4 * (I) + 0], mr);			\
+	mi = fma(xd_, (T)[4 * (I) + 1], mi);			\
+	sr = fma(xd_, (T)[4 * (I) + 2], sr);			\
+	si = fma(xd_, (T)[4 * (I) + 3], si);			\
+    } while (0)
+
+// The two-band correlation of ONE bit window held in a skewed slab (one lane).
+// `rel` is the window start relative to slab row 0.  The twiddle index is
+// uniform across the wave, so the twiddles arrive through the scalar cache; the
+// table is zero-padded to a multiple of XCH and the tail of the last chunk
+// contributes fma(x, 0, acc) == acc (its sample index is clamped so that it
+// never reads LDS that was not staged).
+static_assert(XCH == 8, "twiddle_fetch moves exactly 8 samples' worth");
+
+__device__ __forceinline__ void correlate_window( const DevCfg &cfg, const double *__restrict__ tw,
+	const float *slab, uint32_t rel, bool active, double acc[4] )
+{
+    const uint32_t B = cfg.bit_nsamples;
+    uint32_t row, col;
+    divmod_bit(cfg, rel, row, col);
+    const float *p = slab + rel + row * cfg.skew;
+    const uint32_t last = B - 1;
+    double mr = 0.0, mi = 0.0, sr = 0.0, si = 0.0;
+    if ( __all(!active || col == 0u) ) {
+	// every window of this wave starts on a row boundary: plain
+	// immediate-offset LDS reads, no per-sample address arithmetic
+	for ( uint32_t n0 = 0; n0 < B; n0 += XCH ) {
+	    tw8 ta, tb, tc, td;
+	    twiddle_fetch(tw + 4 * (size_t)n0, ta, tb, tc, td);
+	    float xs[XCH];
+#pragma unroll
+	    for ( int j = 0; j < XCH; j++ )
+		xs[j] = p[n0 + j < last ? n0 + j : last];
+	    twiddle_wait();
+	    MIFSK_FMA4(xs[0], ta, 0);  MIFSK_FMA4(xs[1], ta, 1);
+	    MIFSK_FMA4(xs[2], tb, 0);  MIFSK_FMA4(xs[3], tb, 1);
+	    MIFSK_FMA4(xs[4], tc, 0);  MIFSK_FMA4(xs[5], tc, 1);
+	    MIFSK_FMA4(xs[6], td, 0);  MIFSK_FMA4(xs[7], td, 1);
+	}
+    } else {
+	const uint32_t wrap = B - col;	// first n that falls into the next row
+	const uint32_t skew = cfg.skew;
+	for ( uint32_t n0 = 0; n0 < B; n0 += XCH ) {
+	    tw8 ta, tb, tc, td;
+	    twiddle_fetch(tw + 4 * (size_t)n0, ta, tb, tc, td);
+	    float xs[XCH];
+#pragma unroll
+	    for ( int j = 0; j < XCH; j++ ) {
+		const uint32_t n = n0 + j < last ? n0 + j : last;	// uniform
+		xs[j] = p[n + ( n >= wrap ? skew : 0u )];
+	    }
+	    twiddle_wait();
+	    MIFSK_FMA4(xs[0], ta, 0);  MIFSK_FMA4(xs[1], ta, 1);
+	    MIFSK_FMA4(xs[2], tb, 0);  MIFSK_FMA4(xs[3], tb, 1);
+	    MIFSK_FMA4(xs[4], tc, 0);  MIFSK_FMA4(xs[5], tc, 1);
+	    MIFSK_FMA4(xs[6], td, 0);  MIFSK_FMA4(xs[7], td, 1);
+	}
+    }
+    acc[0] = mr; acc[1] = mi; acc[2] = sr; acc[3] = si;
+}
+
+// Make this wave's LDS writes visible to its other lanes.  LDS operations of one
+// wave execute in order, so no hardware wait is needed; wavefront-scope fences
+// only stop the compiler from reordering across the point.  (An inline-asm
+// wait with a "memory" clobber, or a workgroup-scope fence, makes hipcc drain
+// vmcnt as well -- which would stall on the global loads prefetched for the
+// next batch.)
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ uint32_t wave_min_u32( uint32_t v )
+{
+#pragma unroll
+    for ( int o = 32; o > 0; o >>= 1 ) {
+	const uint32_t t = (uint32_t)__shfl_xor((int)v, o);
+	v = t < v ? t : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_max_u32( uint32_t v )
+{
+#pragma unroll
+    for ( int o = 32; o > 0; o >>= 1 ) {
+	const uint32_t t = (uint32_t)__shfl_xor((int)v, o);
+	v = t > v ? t : v;
+    }
+    return v;
+}
+
+// databits.h:21-46
+__device__ __forceinline__ uint64_t bit_window( uint64_t v, uint32_t offset, uint32_t bits )
+{
+    if ( bits >= 64 )
+	return v >> offset;
+    const uint64_t mask = ( 1ULL << bits ) - 1ULL;
+    return ( v >> offset ) & mask;
+}
+
+__device__ __forceinline__ uint64_t bit_reverse( uint64_t v, uint32_t bits )
+{
+    uint32_t out = 0;		// the reference accumulates in 32 bits
+    while ( bits-- ) {
+	out = ( out << 1 ) | (uint32_t)( v & 1ULL );
+	v >>= 1;
+    }
+    return out;
+}
+
+// frame word -> data bits handed to the databits decoder (minimodem.c:1415-1428)
+__device__ __forceinline__ uint64_t data_bits_of( const DevCfg &cfg, uint64_t bits )
+{
+    if ( cfg.has_stopbits )
+	bits >>= 1;
+    bits = bit_window(bits, cfg.nstartbits, cfg.n_data_bits);
+    if ( cfg.msb_first )
+	bits = bit_reverse(bits, cfg.n_data_bits);
+    return bits;
+}
+
+// v of the lane below (DPP wave_shr:1); lane 0 reads 0
+__device__ __forceinline__ float wave_shr1( float v )
+{
+    const int i = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, i, 0x138, 0xf, 0xf, false));
+}
+
+// The lane scan of the bulk replay (master_loop): `steps` = K - 1 applications of
+//   t <- (t[l-1] + a) * 0.5, pk <- max(pk[l-1], c), sc <- sc[l-1] + c, sa <- sa[l-1] + a
+// with the lower neighbour read through DPP wave_shr:1.  Ping-pong between two
+// register sets (the DPP source is never the destination); lane 0 is left alone
+// by every DPP instruction (no valid source, bound_ctrl off), and `tmp` holds
+// 2 * t in lane 0 so that the plain multiply reproduces its t.  v_max_f32 is the
+// reference's `if (pk < c) pk = c` for every input that can occur (pk is never
+// NaN; a NaN c leaves pk alone in both).  Asm because the compiler neither folds
+// the shuffles into the arithmetic nor keeps lane 0 out of it (15 instructions
+// per step instead of 5).
+// Finally b* (seeded by the caller with the state before frame 0) receive the
+// lower neighbour's result, i.e. the state BEFORE each lane's frame -- inside the
+// asm as well: around a DPP intrinsic the compiler narrows EXEC to the lanes whose
+// result is used, and a lane whose SOURCE lane is masked off is not written.
+__device__ __forceinline__ void replay_scan_asm( float &xt, float &xpk, float &xsc, float &xsa,
+	float &bt, float &bpk, float &bsc, float &bsa, float cv, float av, uint32_t K )
+{
+    float yt = xt, ypk = xpk, ysc = xsc, ysa = xsa;
+    float tmp = xt + xt;
+    const uint32_t pairs = K / 2u;		// 2 * pairs >= K - 1 steps
+#define MIFSK_SCAN_STEP(ST, SPK, SSC, SSA, DT, DPK, DSC, DSA)						\
+	"v_add_f32_dpp %[tmp], " ST ", %[av] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"		\
+	"v_mul_f32_e32 " DT ", 0.5, %[tmp]\n\t"	/* >= 2 instructions before DT is read by DPP */	\
+	"v_max_f32_dpp " DPK ", " SPK ", %[cv] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"		\
+	"v_add_f32_dpp " DSC ", " SSC ", %[cv] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"		\
+	"v_add_f32_dpp " DSA ", " SSA ", %[av] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+    uint32_t n = pairs;
+    // s_nop: a VGPR written by a VALU instruction may be read through DPP only two
+    // wait states later, and the compiler's hazard recogniser does not look into
+    // (or out of) an asm block
+    asm volatile(
+	"s_nop 1\n\t"
+	"s_cmp_eq_u32 %[n], 0\n\t"
+	"s_cbranch_scc1 2f\n\t"
+	"1:\n\t"
+	MIFSK_SCAN_STEP("%[xt]", "%[xpk]", "%[xsc]", "%[xsa]", "%[yt]", "%[ypk]", "%[ysc]", "%[ysa]")
+	"s_sub_u32 %[n], %[n], 1\n\t"
+	MIFSK_SCAN_STEP("%[yt]", "%[ypk]", "%[ysc]", "%[ysa]", "%[xt]", "%[xpk]", "%[xsc]", "%[xsa]")
+	"s_cmp_lg_u32 %[n], 0\n\t"
+	"s_cbranch_scc1 1b\n\t"
+	"s_nop 1\n\t"
+	"2:\n\t"
+	"v_mov_b32_dpp %[bt], %[xt] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+	"v_mov_b32_dpp %[bpk], %[xpk] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+	"v_mov_b32_dpp %[bsc], %[xsc] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+	"v_mov_b32_dpp %[bsa], %[xsa] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+	"s_nop 1\n\t"
+	: [bt] "+v"(bt), [bpk] "+v"(bpk), [bsc] "+v"(bsc), [bsa] "+v"(bsa), [xt] "+v"(xt), [xpk] "+v"(xpk), [xsc] "+v"(xsc), [xsa] "+v"(xsa),
+	  [yt] "+v"(yt), [ypk] "+v"(ypk), [ysc] "+v"(ysc), [ysa] "+v"(ysa),
+	  [tmp] "+v"(tmp), [n] "+s"(n)
+	: [cv] "v"(cv), [av] "v"(av)
+	: "scc");
+#undef MIFSK_SCAN_STEP
+}
+
+__device__ __forceinline__ float lane_bcast( float v, uint32_t src )
+{
+    return __builtin_bit_cast(float,
+	    __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)src));
+}
+
+// LATTICE, linear variant (cfg.lat_linear): the bit length, every bit offset and
+// the frame step are multiples of 4 samples, so every window of the wave starts
+// a multiple of 16 bytes after the first one.  The region then holds the span
+// [lo, hi) unskewed with sample lo at its (16-byte aligned) base:
+//   stage     one (possibly unaligned) 16-byte global load and ONE ds_write_b128
+//             per lane per KiB -- no per-sample address arithmetic at all;
+//   correlate two ds_read_b128 per 8 samples (lanes one bit length apart are
+//             2-way bank conflicted on b128, the same LDS time as the
+//             conflict-free b32 reads of the skewed layout, a quarter of the
+//             instructions).
+// Same arithmetic, same order: results are identical to the skewed variant.
+typedef float float4_u __attribute__((ext_vector_type(4), aligned(4)));
+
+__device__ __forceinline__ float4 load4_unaligned( const float *__restrict__ x, uint32_t a, uint32_t N )
+{
+    const uint32_t aa = ( a + 3 < N && a + 3 >= a ) ? a : 0u;	// tail vectors are re-read by element
+    const float4_u s = *reinterpret_cast<const float4_u *>(x + aa);
+    return make_float4(s.x, s.y, s.z, s.w);
+}
+
+// The correlation loop of the linear variant, software-pipelined over half
+// chunks: while the 16 FMAs of 4 samples issue, the twiddles (scalar cache) and
+// the samples (LDS) of the next 4 are in flight, so neither latency is exposed.
+// One asm statement with fixed registers, because a load whose result is only
+// valid after a LATER s_waitcnt cannot be expressed to the compiler: given
+// separate asm statements it is free to copy or spill the destination registers
+// in between (it did).  Same operations in the same order as MIFSK_FMA4 over
+// samples 0 .. 8 nchunks - 1; the table is zero-padded to whole chunks.
+//   s[34:35] running table pointer, s33 chunks left,
+//   s[36:67] / s[68:99] twiddles of the even / odd half chunk,
+//   v[110:113] / v[114:117] samples of the even / odd half chunk,
+//   v119 running LDS address, v[120:121] the sample as a double.
+typedef __attribute__((address_space(3))) const float lds_cfloat;
+
+#define MIFSK_ASM_FMA4(X, S0, S1, S2, S3)			\
+	"v_cvt_f64_f32_e32 v[120:121], " X "\n\t"		\
+	"v_fmac_f64_e32 %[mr], " S0 ", v[120:121]\n\t"		\
+	"v_fmac_f64_e32 %[mi], " S1 ", v[120:121]\n\t"		\
+	"v_fmac_f64_e32 %[sr], " S2 ", v[120:121]\n\t"		\
+	"v_fmac_f64_e32 %[si], " S3 ", v[120:121]\n\t"
+
+__device__ __forceinline__ void correlate_linear_asm( const double *tw, const float *p,
+	uint32_t nchunks, double &mr, double &mi, double &sr, double &si )
+{
+    const uint32_t tw_lo = (uint32_t)(uintptr_t)tw;
+    const uint32_t tw_hi = (uint32_t)( (uintptr_t)tw >> 32 );
+    const uint32_t addr = (uint32_t)(uintptr_t)(lds_cfloat *)p;
+    asm volatile(
+	"s_mov_b32 s34, %[tlo]\n\t"
+	"s_mov_b32 s35, %[thi]\n\t"
+	"s_mov_b32 s33, %[nch]\n\t"
+	"v_mov_b32_e32 v119, %[addr]\n\t"
+	"s_load_dwordx16 s[36:51], s[34:35], 0x0\n\t"
+	"s_load_dwordx16 s[52:67], s[34:35], 0x40\n\t"
+	"ds_read_b128 v[110:113], v119\n\t"
+	"1:\n\t"
+	"s_waitcnt lgkmcnt(0)\n\t"
+	"s_load_dwordx16 s[68:83], s[34:35], 0x80\n\t"
+	"s_load_dwordx16 s[84:99], s[34:35], 0xc0\n\t"
+	"ds_read_b128 v[114:117], v119 offset:16\n\t"
+	MIFSK_ASM_FMA4("v110", "s[36:37]", "s[38:39]", "s[40:41]", "s[42:43]")
+	MIFSK_ASM_FMA4("v111", "s[44:45]", "s[46:47]", "s[48:49]", "s[50:51]")
+	MIFSK_ASM_FMA4("v112", "s[52:53]", "s[54:55]", "s[56:57]", "s[58:59]")
+	MIFSK_ASM_FMA4("v113", "s[60:61]", "s[62:63]", "s[64:65]", "s[66:67]")
+	"s_add_u32 s34, s34, 0x100\n\t"
+	"s_addc_u32 s35, s35, 0\n\t"
+	"v_add_u32_e32 v119, 32, v119\n\t"
+	"s_sub_u32 s33, s33, 1\n\t"
+	"s_waitcnt lgkmcnt(0)\n\t"
+	"s_cmp_eq_u32 s33, 0\n\t"
+	"s_cbranch_scc1 2f\n\t"
+	"s_load_dwordx16 s[36:51], s[34:35], 0x0\n\t"
+	"s_load_dwordx16 s[52:67], s[34:35], 0x40\n\t"
+	"ds_read_b128 v[110:113], v119\n\t"
+	"2:\n\t"
+	MIFSK_ASM_FMA4("v114", "s[68:69]", "s[70:71]", "s[72:73]", "s[74:75]")
+	MIFSK_ASM_FMA4("v115", "s[76:77]", "s[78:79]", "s[80:81]", "s[82:83]")
+	MIFSK_ASM_FMA4("v116", "s[84:85]", "s[86:87]", "s[88:89]", "s[90:91]")
+	MIFSK_ASM_FMA4("v117", "s[92:93]", "s[94:95]", "s[96:97]", "s[98:99]")
+	"s_cmp_lg_u32 s33, 0\n\t"
+	"s_cbranch_scc1 1b\n\t"
+	: [mr] "+v"(mr), [mi] "+v"(mi), [sr] "+v"(sr), [si] "+v"(si)
+	: [tlo] "s"(tw_lo), [thi] "s"(tw_hi), [nch] "s"(nchunks), [addr] "v"(addr)
+	: "memory", "scc",
+	  "s33", "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45",
+	  "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58",
+	  "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71",
+	  "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84",
+	  "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97",
+	  "s98", "s99",
+	  "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v119", "v120", "v121");
+}
+
+__device__ __forceinline__ void twiddle_fetch_ro( const double *t, tw8 &a, tw8 &b, tw8 &c, tw8 &d )
+{
+    // no "memory" clobber: that would make hipcc drain vmcnt, i.e. wait for the
+    // next chunk's samples right after asking for them
+    asm volatile("s_load_dwordx16 %0, %4, 0x0\n\t"
+		 "s_load_dwordx16 %1, %4, 0x40\n\t"
+		 "s_load_dwordx16 %2, %4, 0x80\n\t"
+		 "s_load_dwordx16 %3, %4, 0xc0"
+		 : "=&s"(a), "=&s"(b), "=&s"(c), "=&s"(d)
+		 : "s"(t));
+}
+
+__device__ __forceinline__ void twiddle_wait_ro()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+} // namespace mifsk

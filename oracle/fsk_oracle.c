@@ -590,7 +590,8 @@ window_bits( unsigned long long value, unsigned int offset, unsigned int bits )
 
 static void
 push_episode( ofsk_rx_result *res, size_t first_frame, unsigned int nframes,
-	size_t carrier_nsamples, float conf_total, float ampl_total, unsigned int reason )
+	size_t carrier_nsamples, float conf_total, float ampl_total, unsigned int reason,
+	unsigned int b_mark )
 {
     if ( res->nepisodes < res->episodes_cap ) {
 	mifsk_episode *e = &res->episodes[res->nepisodes];
@@ -601,6 +602,7 @@ push_episode( ofsk_rx_result *res, size_t first_frame, unsigned int nframes,
 	e->confidence_total = conf_total;
 	e->amplitude_total = ampl_total;
 	e->end_reason = reason;
+	e->b_mark = b_mark;
     }
     res->nepisodes++;
 }
@@ -616,63 +618,6 @@ auto_space_band( const mifsk_rx_config *cfg, const ofsk_plan *p, int carrier_ban
     int b_space = carrier_band + b_shift;
     *b_shift_out = b_shift;
     return !( b_space < 1 || b_space >= (int)p->nbands );
-}
-
-/*
- * --auto-carrier under flat addressing.  Until a carrier is found the loop does
- * nothing but shift and refill its buffer and scan it (minimodem.c:1144-1200),
- * so which windows get scanned is fixed by the buffer arithmetic alone: this
- * replays that arithmetic on (pos = absolute index of samplebuf[0], nvalid)
- * without a buffer.  Returns the band (and *pos_out = where samplebuf[0] sits
- * when it is found: the main search starts there), or -1.
- */
-static int
-auto_carrier_scan_flat( const mifsk_rx_config *cfg, ofsk_plan *p, const float *x, size_t nsamples,
-	size_t *pos_out, int *b_shift_out, unsigned long long *nwin )
-{
-    const size_t bufsize = cfg->samplebuf_size;
-    float nps = cfg->nsamples_per_bit;				/* :1182-1184 */
-    if ( nps > p->fftsize )
-	nps = p->fftsize;
-    size_t pos = 0, nvalid = 0;
-    unsigned int advance = 0;
-    for (;;) {
-	if ( advance == bufsize ) {				/* :1146-1149 */
-	    nvalid = 0;
-	    pos += advance;
-	    advance = 0;
-	}
-	if ( advance ) {					/* :1150-1156 */
-	    if ( advance > nvalid )
-		return -1;
-	    pos += advance;
-	    nvalid -= advance;
-	}
-	if ( nvalid < bufsize / 2 ) {				/* :1158-1174 */
-	    size_t got = pos + nvalid;
-	    size_t r = nsamples - got < bufsize / 2 ? nsamples - got : bufsize / 2;
-	    nvalid += r;
-	}
-	if ( nvalid == 0 )					/* :1176 */
-	    return -1;
-	unsigned int i;
-	int band = -1;
-	for ( i = 0; i + nps <= nvalid; i += nps ) {		/* :1185-1192 */
-	    band = ofsk_detect_carrier(p, x + pos + i, nps, cfg->auto_carrier_threshold);
-	    (*nwin)++;
-	    if ( band >= 0 )
-		break;
-	}
-	advance = i + nps;					/* :1193-1195 */
-	if ( advance > nvalid )
-	    advance = nvalid;
-	if ( band < 0 )
-	    continue;
-	if ( !auto_space_band(cfg, p, band, b_shift_out) )	/* :1209-1213 */
-	    continue;
-	*pos_out = pos;
-	return band;
-    }
 }
 
 int
@@ -691,12 +636,19 @@ ofsk_rx_stream( const mifsk_rx_config *cfg, const float *samples, size_t nsample
     const unsigned int expect_nsamples = cfg->expect_nsamples;
     const size_t bufsize = cfg->samplebuf_size;
 
-    /* flat mode: zero-padded copy of the whole stream */
+    /*
+     * One buffer arithmetic for both modes -- (base, nvalid) = absolute index of
+     * samplebuf[0] and samples_nvalid, evolving exactly as minimodem.c:1144-1174
+     * makes them evolve (the file position is always base + nvalid).  The modes
+     * differ only in what a search sees in cells at or beyond nvalid:
+     *   ring: whatever the reference's buffer holds there (stale samples that
+     *         memmove left behind; zero where nothing was ever written),
+     *   flat: the stream itself, 0.0 beyond its end.
+     */
     size_t pad = 2 * (size_t)expect_nsamples + 4 * (size_t)ceilf(spb) + 64;
     float *buf;
-    size_t rp = 0;		/* ring: next unread input sample */
-    size_t nvalid = 0;		/* ring: samples_nvalid */
-    size_t base = 0;		/* absolute index of buf[0] (ring) / cursor (flat) */
+    size_t nvalid = 0;		/* samples_nvalid */
+    size_t base = 0;		/* absolute index of samplebuf[0] */
     if ( ring_mode ) {
 	buf = calloc(bufsize + pad, sizeof(float));
     } else {
@@ -715,20 +667,7 @@ ofsk_rx_stream( const mifsk_rx_config *cfg, const float *samples, size_t nsample
     res->carrier_b_space = 0;
     res->n_scan_windows = 0;
     const int autodetect = cfg->auto_carrier_threshold > 0.0f;
-    int carrier_band = -1;		/* `static` in the reference: found once per run */
-    if ( autodetect && !ring_mode ) {
-	int b_shift = 0;
-	carrier_band = auto_carrier_scan_flat(cfg, p, buf, nsamples, &base, &b_shift,
-					      &res->n_scan_windows);
-	if ( carrier_band < 0 ) {
-	    free(buf);
-	    ofsk_plan_destroy(p);
-	    return 0;			/* no carrier anywhere: nothing is decoded */
-	}
-	ofsk_set_tones_by_bandshift(p, (unsigned int)carrier_band, b_shift);
-	res->carrier_band = carrier_band;
-	res->carrier_b_space = p->b_space;
-    }
+    int carrier_band = -1;		/* `static int carrier_band = -1` (minimodem.c:1180) */
 
     int carrier = 0;
     float confidence_total = 0, amplitude_total = 0;
@@ -738,44 +677,36 @@ ofsk_rx_stream( const mifsk_rx_config *cfg, const float *samples, size_t nsample
     unsigned int advance = 0;
     float track_amplitude = 0.0f, peak_confidence = 0.0f;
     size_t episode_first_frame = 0;
+    unsigned int episode_b_mark = 0;
 
     for (;;) {
 	float *win;
-	if ( ring_mode ) {
-	    /* minimodem.c:1144-1177 */
-	    if ( advance == bufsize ) {
-		nvalid = 0;
-		base += advance;
-		advance = 0;
-	    }
-	    if ( advance ) {
-		if ( advance > nvalid )
-		    break;
-		memmove(buf, buf + advance, (bufsize - advance) * sizeof(float));
-		nvalid -= advance;
-		base += advance;
-	    }
-	    if ( nvalid < bufsize / 2 ) {
-		size_t want = bufsize / 2;
-		size_t r = nsamples - rp < want ? nsamples - rp : want;
-		memcpy(buf + nvalid, samples + rp, r * sizeof(float));
-		rp += r;
-		nvalid += r;
-	    }
-	    win = buf;
-	} else {
-	    size_t avail = nsamples - base;
-	    if ( advance ) {
-		if ( advance > avail )
-		    break;
-		base += advance;
-	    }
-	    nvalid = nsamples - base;
-	    win = buf + base;
+	/* minimodem.c:1144-1177 */
+	if ( advance == bufsize ) {
+	    nvalid = 0;
+	    base += advance;
+	    advance = 0;
 	}
+	if ( advance ) {
+	    if ( advance > nvalid )
+		break;
+	    if ( ring_mode )
+		memmove(buf, buf + advance, (bufsize - advance) * sizeof(float));
+	    nvalid -= advance;
+	    base += advance;
+	}
+	if ( nvalid < bufsize / 2 ) {
+	    size_t want = bufsize / 2;
+	    size_t rp = base + nvalid;		/* the file position */
+	    size_t r = nsamples - rp < want ? nsamples - rp : want;
+	    if ( ring_mode )
+		memcpy(buf + nvalid, samples + rp, r * sizeof(float));
+	    nvalid += r;
+	}
+	win = ring_mode ? buf : buf + base;
 	if ( nvalid == 0 )
 	    break;
-	if ( autodetect && carrier_band < 0 ) {			/* ring mode only; :1179-1220 */
+	if ( autodetect && carrier_band < 0 ) {			/* :1179-1220 */
 	    unsigned int i;
 	    float nps = spb;
 	    if ( nps > p->fftsize )
@@ -797,8 +728,10 @@ ofsk_rx_stream( const mifsk_rx_config *cfg, const float *samples, size_t nsample
 		continue;
 	    }
 	    ofsk_set_tones_by_bandshift(p, (unsigned int)carrier_band, b_shift);
-	    res->carrier_band = carrier_band;
-	    res->carrier_b_space = p->b_space;
+	    if ( res->carrier_band < 0 ) {		/* the first pair found */
+		res->carrier_band = carrier_band;
+		res->carrier_b_space = p->b_space;
+	    }
 	}
 	if ( nvalid < expect_nsamples )				/* :1229 */
 	    break;
@@ -830,9 +763,10 @@ ofsk_rx_stream( const mifsk_rx_config *cfg, const float *samples, size_t nsample
 
 	if ( confidence <= cfg->confidence_threshold ) {	/* :1292-1321 */
 	    if ( ++noconfidence > 20 ) {
+		carrier_band = -1;				/* :1297: look for the tone again */
 		if ( carrier ) {
 		    push_episode(res, episode_first_frame, nframes_decoded, carrier_nsamples,
-			    confidence_total, amplitude_total, 1);
+			    confidence_total, amplitude_total, 1, episode_b_mark);
 		    carrier = 0;
 		    carrier_nsamples = 0;
 		    confidence_total = 0;
@@ -857,6 +791,7 @@ ofsk_rx_stream( const mifsk_rx_config *cfg, const float *samples, size_t nsample
 	    refine = 1;
 	    flags |= MIFSK_FRAME_ACQUIRE;
 	    episode_first_frame = res->nframes;
+	    episode_b_mark = p->b_mark;				/* :1340,1344: "@ %.1f Hz" */
 	}
 
 	if ( refine ) {						/* :1357-1389 */
@@ -921,7 +856,7 @@ ofsk_rx_stream( const mifsk_rx_config *cfg, const float *samples, size_t nsample
 
     if ( carrier )						/* :1469-1474 */
 	push_episode(res, episode_first_frame, nframes_decoded, carrier_nsamples,
-		confidence_total, amplitude_total, 2);
+		confidence_total, amplitude_total, 2, episode_b_mark);
 
     free(buf);
     ofsk_plan_destroy(p);

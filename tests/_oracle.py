@@ -120,7 +120,7 @@ class Episode(C.Structure):
         ("confidence_total", C.c_float),
         ("amplitude_total", C.c_float),
         ("end_reason", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("b_mark", C.c_uint32),
     ]
 
 
@@ -129,7 +129,7 @@ FRAME_DTYPE = np.dtype([("bits", "<u8"), ("start", "<u8"), ("confidence", "<f4")
 EPISODE_DTYPE = np.dtype([("carrier_nsamples", "<u8"), ("first_frame", "<u4"),
                           ("nframes", "<u4"), ("confidence_total", "<f4"),
                           ("amplitude_total", "<f4"), ("end_reason", "<u4"),
-                          ("reserved", "<u4")])
+                          ("b_mark", "<u4")])
 assert FRAME_DTYPE.itemsize == C.sizeof(Frame) == 32
 assert EPISODE_DTYPE.itemsize == C.sizeof(Episode) == 32
 
