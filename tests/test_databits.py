@@ -79,6 +79,7 @@ def test_stream_text_capacity_and_arguments():
     eps = np.zeros(1, dtype=M.EPISODE_DTYPE)
     eps["nframes"], eps["carrier_nsamples"] = 3, 1200
     eps["confidence_total"], eps["amplitude_total"], eps["end_reason"] = 12.0, 3.0, 2
+    eps["b_mark"] = cfg.b_mark           # the band at acquisition travels with the episode
     out, err = M.stream_text(cfg, bits, eps)
     assert out == b"ABC" and err.startswith("### CARRIER 1200 @ 1200.0 Hz ###\n\n### NOCARRIER ndata=3 ")
     small = C.create_string_buffer(2)
