@@ -207,6 +207,7 @@ typedef struct mifsk_episode {
 
 #define MIFSK_STREAM_FRAMES_TRUNCATED	1u
 #define MIFSK_STREAM_EPISODES_TRUNCATED	2u
+#define MIFSK_STREAM_ABORTED		4u	/* internal error: the loop was cut short */
 
 typedef struct mifsk_demod_io {
     /* inputs */
@@ -232,9 +233,26 @@ typedef struct mifsk_demod_io {
 					   counters (MIFSK_CNT_*) or NULL    */
     int32_t		*d_carrier_band;/* [nstreams] or NULL; --auto-carrier
 					   only: the band the mark tone was
-					   detected in, -1 = no carrier found
-					   (the stream then yields nothing)  */
+					   FIRST detected in, -1 = never (the
+					   stream then yields nothing); later
+					   re-detections (minimodem.c:1297)
+					   show in mifsk_episode.b_mark      */
+    uint32_t		flags;		/* MIFSK_IO_*                        */
+    uint32_t		reserved;	/* 0                                 */
 } mifsk_demod_io;
+
+/* Buffer addressing of a search that reads past samples_nvalid (minimodem.c:
+ * 1153,1229; fsk.c:204-206).  Default ("flat"): it sees the stream itself and
+ * 0.0 beyond the stream's end.  MIFSK_IO_RING_EXACT: it sees what the
+ * reference's samplebuf holds there -- the stale cells memmove left behind,
+ * 0.0 where nothing was ever written (the reference: uninitialised heap) -- the
+ * reference's buffer is kept cell for cell in device memory and every frame
+ * goes through the general path: exact, and several times slower. */
+#define MIFSK_IO_RING_EXACT	1u
+/* Run the receive loop with one 256-thread workgroup per stream (master wave +
+ * worker waves; the round-1 kernel) instead of one wavefront per stream.
+ * Flat addressing only; --auto-carrier looks for the tone once per stream. */
+#define MIFSK_IO_ENGINE_WORKGROUP 2u
 
 /* per-stream work counters (diagnostics; cycle counts are s_memtime ticks) */
 #define MIFSK_NCOUNTERS		24

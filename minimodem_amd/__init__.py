@@ -124,7 +124,8 @@ def max_frames(cfg, nsamples):
 
 
 def demod_batch(ctx, cfg, samples, nsamples=None, want=("bytes", "episodes"),
-                frames_cap=None, episodes_cap=8, stream=None, out=None):
+                frames_cap=None, episodes_cap=8, stream=None, out=None, ring_exact=False,
+                engine=None):
     """Run the receive loop over a batch of streams resident in HBM.
 
     samples : torch.float32 CUDA tensor [nstreams, stride] (stride % 4 == 0)
@@ -132,6 +133,9 @@ def demod_batch(ctx, cfg, samples, nsamples=None, want=("bytes", "episodes"),
     Returns a dict of CUDA tensors (no synchronisation is performed).
     `out` may be a dict returned by a previous call with the same shapes, to
     reuse its buffers (nothing is allocated inside the timed region then).
+    ring_exact: MIFSK_IO_RING_EXACT (the reference's stale-cell buffer semantics).
+    engine: None (one wavefront per stream) or "workgroup" (one 256-thread
+    workgroup per stream, MIFSK_IO_ENGINE_WORKGROUP).
     """
     torch = _torch()
     lib = _lib.load()
@@ -188,6 +192,8 @@ def demod_batch(ctx, cfg, samples, nsamples=None, want=("bytes", "episodes"),
     io.d_status = ptr("status")
     io.d_counters = ptr("counters")
     io.d_carrier_band = ptr("carrier_band")
+    io.flags = (_lib.IO_RING_EXACT if ring_exact else 0) | \
+        (_lib.IO_ENGINE_WORKGROUP if engine == "workgroup" else 0)
     rc = lib.mifsk_demod_batch(ctx.handle, C.byref(cfg), C.byref(io), _stream_ptr(torch, stream))
     if rc != 0:
         raise RuntimeError("mifsk_demod_batch failed: %d" % rc)
@@ -506,7 +512,8 @@ def synthesize_batch(ctx, cfg, words, nwords=None, lut=4096, amplitude=1.0, lead
     return out, lens
 
 
-def demod_batch_host(ctx, cfg, samples, nsamples=None, frames_cap=None, episodes_cap=8):
+def demod_batch_host(ctx, cfg, samples, nsamples=None, frames_cap=None, episodes_cap=8,
+                     ring_exact=False):
     """mifsk_demod_batch_host: the whole batch from HOST memory in one call (copies
     in, runs the receive loop on the device, copies out, synchronises).  samples is a
     float32 numpy array [nstreams, stride]; returns a dict of numpy arrays."""
@@ -545,6 +552,7 @@ def demod_batch_host(ctx, cfg, samples, nsamples=None, frames_cap=None, episodes
     io.episodes_cap = episodes_cap
     io.d_status = res["status"].ctypes.data
     io.d_carrier_band = res["carrier_band"].ctypes.data
+    io.flags = _lib.IO_RING_EXACT if ring_exact else 0
     rc = lib.mifsk_demod_batch_host(ctx.handle, C.byref(cfg), C.byref(io))
     if rc != 0:
         raise RuntimeError("mifsk_demod_batch_host failed: %d" % rc)

@@ -132,7 +132,12 @@ class DemodIO(C.Structure):
         ("d_status", C.c_void_p),
         ("d_counters", C.c_void_p),
         ("d_carrier_band", C.c_void_p),
+        ("flags", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
+
+IO_RING_EXACT = 1
+IO_ENGINE_WORKGROUP = 2
 
 
 class FskPlan(C.Structure):

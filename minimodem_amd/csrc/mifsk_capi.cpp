@@ -388,6 +388,63 @@ static int demod_batch_auto( mifsk_ctx *ctx, const mifsk_rx_config *cfg, const D
 				     ctx->d_auto_start);
 }
 
+// One wavefront per stream (mifsk_wave.hip): --auto-carrier and RING addressing
+// need per-call device scratch; it is allocated and freed in stream order, so
+// concurrent calls on different streams never share it.
+static int demod_batch_wave( mifsk_ctx *ctx, const mifsk_rx_config *cfg, const DevCfg &d,
+	const DevCfg *d_cfg, const double *d_tw, const mifsk_demod_io *io, void *stream )
+{
+    hipStream_t st = (hipStream_t)stream;
+    const size_t ns = (size_t)io->nstreams;
+    mifsk::WaveHostArgs ha;
+    std::memset(&ha, 0, sizeof(ha));
+    ha.samplebuf_size = cfg->samplebuf_size;
+    ha.fftsize = (uint32_t)cfg->fftsize;
+    ha.nbands = cfg->nbands;
+    ha.tw_entries = (uint32_t)( ( ( (size_t)cfg->bit_nsamples + 7 ) & ~(size_t)7 ) + 8 );
+    void *scratch_tw = nullptr, *scratch_ring = nullptr;
+    if ( cfg->auto_carrier_threshold > 0.0f ) {
+	// default negative shift, in the reference's float arithmetic (minimodem.c:1203-1206)
+	int b_shift = - (float)( cfg->autodetect_shift + cfg->band_width / 2.0f ) / cfg->band_width;
+	if ( cfg->inverted_freqs )
+	    b_shift *= -1;
+	if ( b_shift == 0 )
+	    return -EINVAL;			// assert in fsk_set_tones_by_bandshift (fsk.c:587)
+	if ( (unsigned long long)cfg->nbands * cfg->bit_nsamples > 0xFFFFFFFFull )
+	    return -EINVAL;			// (band * n is reduced in 32 bits on the device)
+	const double *d_cs = nullptr;
+	int rc = get_cs(ctx, (unsigned)cfg->fftsize, &d_cs);
+	if ( rc )
+	    return rc;
+	ha.autodetect = true;
+	ha.auto_threshold = cfg->auto_carrier_threshold;
+	ha.nps = cfg->nsamples_per_bit > (float)cfg->fftsize ? (float)cfg->fftsize
+							      : cfg->nsamples_per_bit;
+	ha.b_shift = b_shift;
+	ha.d_cs = d_cs;
+	if ( hipMallocAsync(&scratch_tw, ns * ha.tw_entries * 4 * sizeof(double), st) != hipSuccess )
+	    return -ENOMEM;
+	ha.d_tw_scratch = (double *)scratch_tw;
+    }
+    if ( io->flags & MIFSK_IO_RING_EXACT ) {
+	// samplebuf plus what a search at the top of it may touch beyond
+	const size_t reach = (size_t)( cfg->try_max[0] > cfg->try_max[1] ? cfg->try_max[0] : cfg->try_max[1] )
+			   + d.last_reach + 64;
+	ha.ring_exact = true;
+	ha.ring_stride = (uint32_t)( ( (size_t)cfg->samplebuf_size + reach + 3 ) & ~(size_t)3 );
+	if ( hipMallocAsync(&scratch_ring, ns * ha.ring_stride * sizeof(float), st) != hipSuccess
+		|| hipMemsetAsync(scratch_ring, 0, ns * ha.ring_stride * sizeof(float), st) != hipSuccess ) {
+	    if ( scratch_tw ) (void)hipFreeAsync(scratch_tw, st);
+	    return -ENOMEM;
+	}
+	ha.d_ring = (float *)scratch_ring;
+    }
+    const int rc = mifsk::launch_demod_wave(d, d_cfg, d_tw, *io, ha, stream);
+    if ( scratch_tw ) (void)hipFreeAsync(scratch_tw, st);
+    if ( scratch_ring ) (void)hipFreeAsync(scratch_ring, st);
+    return rc;
+}
+
 extern "C" int mifsk_demod_batch( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
 	const mifsk_demod_io *io, void *stream )
 {
@@ -398,6 +455,10 @@ extern "C" int mifsk_demod_batch( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
     if ( io->stream_stride % 4 != 0 || ( (uintptr_t)io->d_samples & 15u ) )
 	return -EINVAL;		// rows must be 16-byte aligned (coalesced float4 staging)
     if ( ( io->d_bytes || io->d_bits || io->d_frames ) && io->frames_cap == 0 )
+	return -EINVAL;
+    if ( io->flags & ~( MIFSK_IO_RING_EXACT | MIFSK_IO_ENGINE_WORKGROUP ) )
+	return -EINVAL;
+    if ( ( io->flags & MIFSK_IO_RING_EXACT ) && ( io->flags & MIFSK_IO_ENGINE_WORKGROUP ) )
 	return -EINVAL;
     HIP_OK(hipSetDevice(ctx->device));
     const double *d_tw = nullptr;
@@ -411,7 +472,14 @@ extern "C" int mifsk_demod_batch( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
     rc = get_devcfg(ctx, d, &d_cfg);
     if ( rc )
 	return rc;
-    if ( cfg->auto_carrier_threshold > 0.0f && io->nstreams > 0 )
+    if ( io->nstreams == 0 )
+	return 0;
+    bool workgroup = ( io->flags & MIFSK_IO_ENGINE_WORKGROUP ) != 0;
+    if ( const char *e = std::getenv("MIFSK_ENGINE") )	// diagnostic override: "workgroup" / "wave"
+	workgroup = e[0] == 'w' && e[1] == 'o' && !( io->flags & MIFSK_IO_RING_EXACT );
+    if ( !workgroup )
+	return demod_batch_wave(ctx, cfg, d, d_cfg, d_tw, io, stream);
+    if ( cfg->auto_carrier_threshold > 0.0f )
 	return demod_batch_auto(ctx, cfg, d, d_cfg, d_tw, io, stream);
     return mifsk::launch_demod_batch(d, d_cfg, d_tw, *io, stream);
 }

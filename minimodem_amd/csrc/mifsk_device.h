@@ -64,6 +64,56 @@ int launch_demod_batch( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_
 	const mifsk_demod_io &io, void *stream,
 	const double *const *d_tw_v = nullptr, const uint32_t *d_start_v = nullptr );
 
+// ---- one wavefront per stream (mifsk_wave.hip) ---------------------------
+
+enum { LAT_NONE = 0u, LAT_LINEAR = 1u, LAT_DIRECT = 2u };	// how a LATTICE block gets at the samples
+
+// launch geometry and run-time options of demod_wave_kernel (by value: SGPRs)
+struct WaveGeom {
+    uint32_t	mags_cap;	// LDS: (mark, space) magnitude slots
+    uint32_t	slab_floats;	// LDS: floats in the sample slab
+    uint32_t	slab_cap;	// samples a skewed SCAN slab holds (0: SCAN streams from global memory)
+    uint32_t	lat_mode;	// LAT_*
+    uint32_t	lat_fmax;	// frames per LATTICE block, at most (<= 64)
+    uint32_t	lat_fmin;	// ... and at least (one pass of lanes)
+    uint32_t	round_wins;	// LINEAR: bit windows per staging round
+    uint32_t	bufsize;	// the reference's samplebuf_size (minimodem.c:1063-1070)
+    uint32_t	ring_exact;	// RING addressing (stale-cell semantics)
+    uint32_t	ring_stride;	// floats per stream in the device-resident samplebuf
+    // --auto-carrier (minimodem.c:1179-1220)
+    uint32_t	autodetect;
+    float	auto_threshold;
+    float	nps;		// nsamples_per_scan = min(nsamples_per_bit, fftsize)
+    int32_t	b_shift;	// space band = mark band + b_shift
+    uint32_t	fftsize, nbands;
+    uint32_t	tw_entries;	// samples per per-stream twiddle table
+};
+
+struct WaveAuto {
+    const double	*d_cs;		// [fftsize][2]: cos, -sin of 2 pi k / fftsize
+    double		*d_tw_scratch;	// [nstreams][tw_entries][4]
+    float		*d_ring;	// [nstreams][ring_stride], zero-initialised
+};
+
+// what the host glue hands the launcher besides cfg / io
+struct WaveHostArgs {
+    uint32_t	samplebuf_size;
+    bool	ring_exact;
+    uint32_t	ring_stride;
+    float	*d_ring;
+    bool	autodetect;
+    float	auto_threshold;
+    float	nps;
+    int32_t	b_shift;
+    uint32_t	fftsize, nbands;
+    uint32_t	tw_entries;
+    const double *d_cs;
+    double	*d_tw_scratch;
+};
+
+int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_tw,
+	const mifsk_demod_io &io, const WaveHostArgs &ha, void *stream );
+
 // --auto-carrier scan (mifsk_carrier.hip): per stream the band the mark tone is
 // first detected in (-1: never) and the cursor the receive loop starts at
 struct CarrierScanArgs {

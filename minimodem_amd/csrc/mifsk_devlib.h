@@ -193,6 +193,14 @@ frame_confidence_any( const float2 *mags, uint64_t req_mask, uint64_t req_val, u
     return frame_confidence(mags, req_mask, req_val, n_bits);
 }
 
+// what one fsk_find_frame() returns (fsk.c:504-511)
+struct ScanResult {
+    float	conf;
+    float	ampl;
+    uint64_t	bits;
+    uint32_t	start;
+};
+
 // The reference's zig-zag scan order (fsk.c:477-484): first, first+s, first-s,
 // first+2s, first-2s, ...; an up-step reaching try_max ends the scan, a
 // down-step below 0 is skipped.  Closed form: U up-positions (u = 0..U-1),
@@ -615,6 +623,72 @@ __device__ __forceinline__ void correlate_linear_asm( const double *tw, const fl
 	"s_cbranch_scc1 1b\n\t"
 	: [mr] "+v"(mr), [mi] "+v"(mi), [sr] "+v"(sr), [si] "+v"(si)
 	: [tlo] "s"(tw_lo), [thi] "s"(tw_hi), [nch] "s"(nchunks), [addr] "v"(addr)
+	: "memory", "scc",
+	  "s33", "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45",
+	  "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58",
+	  "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71",
+	  "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84",
+	  "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97",
+	  "s98", "s99",
+	  "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v119", "v120", "v121");
+}
+
+// The same loop with HALF-chunk granularity (4 samples): `nhalf` >= 1 half chunks
+// are consumed, so a window of B samples costs ceil(B / 4) half chunks instead of
+// ceil(B / 8) whole ones -- at 12000 baud (B = 4) that halves the FMAs.  The
+// table must be readable one half chunk beyond the last one consumed (it is
+// padded by a whole chunk).  Same operations, same order.
+__device__ __forceinline__ void correlate_linear_asm_h( const double *tw, const float *p,
+	uint32_t nhalf, double &mr, double &mi, double &sr, double &si )
+{
+    const uint32_t tw_lo = (uint32_t)(uintptr_t)tw;
+    const uint32_t tw_hi = (uint32_t)( (uintptr_t)tw >> 32 );
+    const uint32_t addr = (uint32_t)(uintptr_t)(lds_cfloat *)p;
+    asm volatile(
+	"s_mov_b32 s34, %[tlo]\n\t"
+	"s_mov_b32 s35, %[thi]\n\t"
+	"s_mov_b32 s33, %[nh]\n\t"
+	"v_mov_b32_e32 v119, %[addr]\n\t"
+	"s_load_dwordx16 s[36:51], s[34:35], 0x0\n\t"
+	"s_load_dwordx16 s[52:67], s[34:35], 0x40\n\t"
+	"ds_read_b128 v[110:113], v119\n\t"
+	"1:\n\t"
+	"s_waitcnt lgkmcnt(0)\n\t"
+	"s_cmp_eq_u32 s33, 1\n\t"
+	"s_cbranch_scc1 3f\n\t"
+	"s_load_dwordx16 s[68:83], s[34:35], 0x80\n\t"
+	"s_load_dwordx16 s[84:99], s[34:35], 0xc0\n\t"
+	"ds_read_b128 v[114:117], v119 offset:16\n\t"
+	MIFSK_ASM_FMA4("v110", "s[36:37]", "s[38:39]", "s[40:41]", "s[42:43]")
+	MIFSK_ASM_FMA4("v111", "s[44:45]", "s[46:47]", "s[48:49]", "s[50:51]")
+	MIFSK_ASM_FMA4("v112", "s[52:53]", "s[54:55]", "s[56:57]", "s[58:59]")
+	MIFSK_ASM_FMA4("v113", "s[60:61]", "s[62:63]", "s[64:65]", "s[66:67]")
+	"s_add_u32 s34, s34, 0x100\n\t"
+	"s_addc_u32 s35, s35, 0\n\t"
+	"v_add_u32_e32 v119, 32, v119\n\t"
+	"s_sub_u32 s33, s33, 2\n\t"
+	"s_waitcnt lgkmcnt(0)\n\t"
+	"s_cmp_eq_u32 s33, 0\n\t"
+	"s_cbranch_scc1 2f\n\t"
+	"s_load_dwordx16 s[36:51], s[34:35], 0x0\n\t"
+	"s_load_dwordx16 s[52:67], s[34:35], 0x40\n\t"
+	"ds_read_b128 v[110:113], v119\n\t"
+	"2:\n\t"
+	MIFSK_ASM_FMA4("v114", "s[68:69]", "s[70:71]", "s[72:73]", "s[74:75]")
+	MIFSK_ASM_FMA4("v115", "s[76:77]", "s[78:79]", "s[80:81]", "s[82:83]")
+	MIFSK_ASM_FMA4("v116", "s[84:85]", "s[86:87]", "s[88:89]", "s[90:91]")
+	MIFSK_ASM_FMA4("v117", "s[92:93]", "s[94:95]", "s[96:97]", "s[98:99]")
+	"s_cmp_lg_u32 s33, 0\n\t"
+	"s_cbranch_scc1 1b\n\t"
+	"s_branch 4f\n\t"
+	"3:\n\t"
+	MIFSK_ASM_FMA4("v110", "s[36:37]", "s[38:39]", "s[40:41]", "s[42:43]")
+	MIFSK_ASM_FMA4("v111", "s[44:45]", "s[46:47]", "s[48:49]", "s[50:51]")
+	MIFSK_ASM_FMA4("v112", "s[52:53]", "s[54:55]", "s[56:57]", "s[58:59]")
+	MIFSK_ASM_FMA4("v113", "s[60:61]", "s[62:63]", "s[64:65]", "s[66:67]")
+	"4:\n\t"
+	: [mr] "+v"(mr), [mi] "+v"(mi), [sr] "+v"(sr), [si] "+v"(si)
+	: [tlo] "s"(tw_lo), [thi] "s"(tw_hi), [nh] "s"(nhalf), [addr] "v"(addr)
 	: "memory", "scc",
 	  "s33", "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45",
 	  "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58",

@@ -172,7 +172,6 @@ __device__ __forceinline__ void lds_barrier();
 __device__ __forceinline__ float lane_bcast( float v, uint32_t src );
 
 constexpr int NWORKERS = 3;
-enum { LAT_NONE = 0u, LAT_LINEAR = 1u, LAT_DIRECT = 2u };	// how the workers get at the samples
 constexpr int LAT_LANES = NWORKERS * 64;	// bit windows per lattice batch
 
 struct StreamLds {
@@ -203,12 +202,6 @@ struct StreamLds {
 
 enum { CMD_EXIT = 0, CMD_SCAN = 1, CMD_LATTICE = 2, CMD_IDLE = 3 };
 
-struct ScanResult {
-    float	conf;
-    float	ampl;
-    uint64_t	bits;
-    uint32_t	start;
-};
 
 
 

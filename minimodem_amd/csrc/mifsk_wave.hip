@@ -1,0 +1,1246 @@
+// mifsk_wave.hip -- the receive loop, ONE WAVEFRONT PER STREAM (gfx950 / CDNA4).
+//
+// The reference's loop (src/minimodem.c:1137-1463) is a serial, data-dependent
+// cursor per stream; streams are independent.  MI355X has 1024 SIMDs and every
+// BASELINE workload has at least 1024 streams, so the natural mapping is one
+// 64-lane wavefront per stream: a workgroup IS a wave.  Nothing is ever
+// exchanged between waves -- no s_barrier, no command block, no idle master --
+// and the SIMDs are kept busy by however many independent streams are resident
+// (1 to 4 waves per SIMD, decided by the LDS each needs).
+//
+// Inside the wave the 64 lanes are used three ways:
+//   correlate   one lane = one bit window: two complex dot products against the
+//               mark / space twiddles, f64 fma in index order (fsk.c:117-174 is a
+//               zero-padded FFT read at two bins; mifsk_devlib.h).  The twiddle
+//               index is uniform, so twiddles come through the scalar cache.
+//   score       one lane = one candidate frame: fsk_frame_analyze's confidence
+//               (fsk.c:271-342) over that frame's magnitudes.
+//   replay      one lane = one frame of a LATTICE block: the loop's f32 state
+//               recurrences replayed in frame order as a DPP lane scan.
+//
+// LATTICE blocks: while carrier is held the next frame is first looked for
+// exactly lock_advance samples after the last (minimodem.c:1263,1407) and that
+// first try ends the search whenever it reaches the search limit (fsk.c:499).
+// So the wave evaluates a block of up to 64 consecutive lattice frames at once
+// -- audio staged through LDS in coalesced 16-byte loads with the next round's
+// loads already in flight, or streamed per lane for long windows -- scores them,
+// and replays the reference's decisions over them; the first frame that fails a
+// predicate goes through the general path (fsk_find_frame as a SCAN of all
+// candidates followed by the reference's selection in scan order), which
+// recomputes from the samples.  Results never depend on the speculation.
+//
+// Buffer arithmetic: (base, rp) = absolute index of samplebuf[0] and the file
+// position; samples_nvalid = rp - base evolves exactly as minimodem.c:1144-1174
+// makes it.  FLAT addressing (default): a search that reads past samples_nvalid
+// sees the stream itself, 0.0 beyond its end.  RING addressing
+// (MIFSK_IO_RING_EXACT): the reference's samplebuf is kept cell for cell in
+// device memory (memmove and half-buffer refills included), so such reads see
+// the stale cells the reference sees.
+//
+// --auto-carrier (minimodem.c:1179-1220,1297): fsk_detect_carrier runs inside
+// the loop whenever no band is held -- also again after 21 searches without
+// confidence -- and the stream's twiddle table is rebuilt on the device for the
+// (mark, space) pair found.
+#include <hip/hip_runtime.h>
+#include <cfloat>
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+
+#include "mifsk_device.h"
+#include "mifsk_devmath.h"
+#include "mifsk_devlib.h"
+
+#ifdef MIFSK_PROFILE
+#define MIFSK_WCLOCK() ((uint32_t)clock64())
+#else
+#define MIFSK_WCLOCK() 0u
+#endif
+
+namespace mifsk {
+
+// A staging round of the linear LATTICE loads SV float4 per lane (SV KiB per
+// wave).  Two instantiations: 10 where a wave can have 10 KiB of LDS for it
+// (1024 streams on 256 CUs leave each wave a quarter of a CU's LDS), 4 where
+// sixteen waves share a CU.
+
+struct WaveOut {
+    uint8_t		*bytes;
+    uint64_t		*bits;
+    mifsk_frame		*frames;
+    mifsk_episode	*eps;
+    uint32_t		fcap, ecap;
+};
+
+// ---------------------------------------------------------------------------
+// fsk_detect_carrier over one window (fsk.c:543-581): the band (>= 1) with the
+// largest magnitude among those not below the threshold, the lowest such band
+// on a tie (the reference keeps the first strict maximum), or -1.  One band per
+// lane per pass; X[b] = sum_n x[n] e^{-2 pi i (b n mod N)/N} in f64 fma, n
+// ascending -- the oracle's sums in the oracle's order.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int wave_detect_window( const float *__restrict__ w, uint32_t n_win,
+	const double *__restrict__ cs, uint32_t fftsize, uint32_t nbands, float threshold )
+{
+    const uint32_t lane = threadIdx.x;
+    const float magscalar = 1.0f / ( (float)n_win / 2.0f );		// fsk.c:553
+    float best = 0.0f;
+    int best_band = -1;
+    for ( uint32_t b0 = 1u; b0 < nbands; b0 += 64u ) {
+	const uint32_t b = b0 + lane;
+	const bool active = b < nbands;
+	const uint32_t bb = active ? b : 1u;
+	double re = 0.0, im = 0.0;
+	uint32_t k = 0;						// (b * n) mod fftsize
+	for ( uint32_t n = 0; n < n_win; n++ ) {
+	    const double x = (double)w[n];			// one address for the whole wave
+	    re = fma(x, cs[2 * (size_t)k], re);
+	    im = fma(x, cs[2 * (size_t)k + 1], im);
+	    k += bb;
+	    if ( k >= fftsize )
+		k -= fftsize;
+	}
+	const float mag = band_mag(re, im, magscalar);
+	if ( active && !( mag < threshold ) && best < mag ) {	// fsk.c:570-575 (ascending bands per lane)
+	    best = mag;
+	    best_band = (int)b;
+	}
+    }
+    // first strict maximum over all bands = largest magnitude, lowest band on ties
+#pragma unroll
+    for ( int o = 32; o > 0; o >>= 1 ) {
+	const float m2 = __shfl_xor(best, o);
+	const int b2 = __shfl_xor(best_band, o);
+	const bool take = b2 >= 0 && ( best_band < 0 || m2 > best || ( m2 == best && b2 < best_band ) );
+	if ( take ) {
+	    best = m2;
+	    best_band = b2;
+	}
+    }
+    return __builtin_amdgcn_readfirstlane(best_band);
+}
+
+// everything the kernel keeps per stream beyond the loop's scalars
+template <int SV>
+struct Wave {
+    static constexpr uint32_t kRoundFloats = 64u * SV * 4u;	// samples one staging round loads
+    const DevCfg	&cfg;
+    const WaveGeom	&g;
+    const double	*tw;
+    const float		*x;		// this stream's samples
+    uint32_t		N;		// its length
+    float2		*mags;		// LDS: (mark, space) magnitude per bit window
+    float		*slab;		// LDS: staged samples
+    float		*ring;		// RING addressing: the reference's samplebuf in device memory
+    uint32_t		lane;
+    uint32_t		safe_limit;	// how far this row may be over-read (whole-round loads)
+    // SCAN slab: absolute range currently staged (skewed layout)
+    uint32_t		slab_lo, slab_hi;
+    // LATTICE block held in registers: lane f = the frame whose first try sits at
+    // lat_anchor + f * lock_advance, for f < lat_n
+    float		l_conf, l_ampl;
+    uint64_t		l_bits;
+    uint32_t		lat_n, lat_anchor;
+    // how far to speculate: frames per block
+    uint32_t		spec, run, cold, pause;
+    // register prefetch of the next LINEAR round
+    float4		pbuf[SV];
+    uint32_t		pref_lo;
+    // counters
+    uint32_t		n_blocks, n_scans, n_positions, n_hits, n_stages;
+    uint32_t		cyc_block, cyc_scan;
+
+    __device__ __forceinline__ Wave( const DevCfg &c, const WaveGeom &gg, const double *t,
+	    const float *xs, uint32_t n, float2 *m, float *s, float *r, uint32_t safe )
+	: cfg(c), g(gg), tw(t), x(xs), N(n), mags(m), slab(s), ring(r), lane(threadIdx.x),
+	  safe_limit(safe), slab_lo(0), slab_hi(0), l_conf(0.0f), l_ampl(0.0f), l_bits(0),
+	  lat_n(0), lat_anchor(0), spec(gg.lat_fmin), run(0), cold(0), pause(0),
+	  pref_lo(0xFFFFFFFFu), n_blocks(0), n_scans(0), n_positions(0), n_hits(0), n_stages(0),
+	  cyc_block(0), cyc_scan(0)
+    {
+#pragma unroll
+	for ( int i = 0; i < SV; i++ )
+	    pbuf[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+
+    // nothing prefetched is wanted any more: end the registers' live ranges
+    __device__ __forceinline__ void drop_prefetch()
+    {
+	pref_lo = 0xFFFFFFFFu;
+#pragma unroll
+	for ( int i = 0; i < SV; i++ )
+	    pbuf[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+
+    // index of the scored lattice frame whose first try is at p, or ~0u
+    __device__ __forceinline__ uint32_t lattice_lookup( uint32_t p ) const
+    {
+	if ( !lat_n || p < lat_anchor )
+	    return ~0u;
+	const uint32_t d = p - lat_anchor;
+	const uint32_t e = udiv_magic(d, cfg.lock_advance, cfg.la_magic);
+	return ( e < lat_n && e * cfg.lock_advance == d ) ? e : ~0u;
+    }
+
+    // window w of a block: start relative to the block's anchor
+    __device__ __forceinline__ uint32_t win_rel( uint32_t w ) const
+    {
+	if ( cfg.lat_grid )
+	    return w * cfg.bit_nsamples;
+	const uint32_t f = udiv_magic(w, cfg.n_bits, cfg.nbits_magic);
+	return f * cfg.lock_advance + cfg.bit_offset[( w - f * cfg.n_bits ) & 63u];
+    }
+
+    // ------------------------------------------------------------------
+    // LATTICE, linear variant: bit length, bit offsets and frame step are
+    // multiples of 4 samples, so every window of a round starts a multiple of
+    // 16 bytes after the round's first sample.  A round = the windows whose
+    // span fits one staging pass of 64 x STAGE_VEC float4: one (possibly
+    // unaligned) 16-byte global load and one ds_write_b128 per lane per KiB,
+    // then one lane per window reading ds_read_b128.  The next round's loads
+    // are issued before this round is correlated and consumed a round later.
+    // ------------------------------------------------------------------
+    __device__ __forceinline__ void round_linear( uint32_t A, uint32_t w0, uint32_t nw, uint32_t next_lo )
+    {
+	const uint32_t B = cfg.bit_nsamples;
+	const uint32_t lo = A + win_rel(w0);			// uniform
+	// Raw loads of one round: 64 * SV consecutive float4 from sample
+	// `from`, whatever the round really needs -- no per-lane bounds logic.
+	// `safe_limit` (>= N) is how far this row may be over-read without leaving
+	// the batch's allocation; a round that would cross it is fetched from
+	// sample 0 instead and its data never used (it reaches the end of the
+	// stream, so it is re-read by element below).
+	if ( pref_lo != lo ) {
+	    const bool ok = lo <= safe_limit - kRoundFloats;
+	    const float *pb = x + ( ok ? lo : 0u ) + ( lane << 2 );
+#pragma unroll
+	    for ( int i = 0; i < SV; i++ ) {
+		const float4_u sv = *reinterpret_cast<const float4_u *>(pb + i * 256);
+		pbuf[i] = make_float4(sv.x, sv.y, sv.z, sv.w);
+	    }
+	}
+	float *lane_base = slab + ( lane << 2 );
+	const uint32_t elast = lo + kRoundFloats;
+	if ( elast <= N && elast >= lo ) {
+#pragma unroll
+	    for ( int i = 0; i < SV; i++ )
+		*reinterpret_cast<float4 *>(lane_base + i * 256) = pbuf[i];
+	} else {
+	    // the round reaches the end of the stream: by element, 0.0 beyond it
+#pragma unroll
+	    for ( int i = 0; i < SV; i++ ) {
+		const uint32_t e = lo + ( ( i * 64 + lane ) << 2 );
+		float4 sv;
+		sv.x = ( e < N ) ? x[e] : 0.0f;
+		sv.y = ( e + 1 < N && e + 1 > e ) ? x[e + 1] : 0.0f;
+		sv.z = ( e + 2 < N && e + 2 > e ) ? x[e + 2] : 0.0f;
+		sv.w = ( e + 3 < N && e + 3 > e ) ? x[e + 3] : 0.0f;
+		*reinterpret_cast<float4 *>(lane_base + i * 256) = sv;
+	    }
+	}
+	// the next round (of this block or, speculatively, of the block after it);
+	// issued unconditionally, no control flow after it that joins before the
+	// correlator (a join makes hipcc drain vmcnt)
+	{
+	    const bool ok = next_lo >= lo && next_lo <= safe_limit - kRoundFloats;
+	    const float *pb = x + ( ok ? next_lo : 0u ) + ( lane << 2 );
+#pragma unroll
+	    for ( int i = 0; i < SV; i++ ) {
+		const float4_u sv = *reinterpret_cast<const float4_u *>(pb + i * 256);
+		pbuf[i] = make_float4(sv.x, sv.y, sv.z, sv.w);
+	    }
+	    pref_lo = ok ? next_lo : 0xFFFFFFFFu;
+	}
+	wave_lds_sync();
+	const uint32_t nhalf = ( B + 3u ) >> 2;
+	for ( uint32_t s0 = 0; s0 < nw; s0 += 64u ) {
+	    const uint32_t w = w0 + s0 + lane;
+	    const bool active = s0 + lane < nw;
+	    const uint32_t rel = A + win_rel(active ? w : w0) - lo;	// idle lanes shadow the first window
+	    double mr = 0.0, mi = 0.0, sr = 0.0, si = 0.0;
+	    correlate_linear_asm_h(tw, slab + rel, nhalf, mr, mi, sr, si);
+	    if ( active )
+		mags[w] = make_float2(band_mag(mr, mi, cfg.magscalar), band_mag(sr, si, cfg.magscalar));
+	}
+	wave_lds_sync();			// the slab is rewritten by the next round
+    }
+
+    // LATTICE, direct variant: any bit length, no LDS staging.  One lane per bit
+    // window; the lane streams ITS OWN window straight from global memory, 32
+    // bytes per step with the next chunk already in flight; twiddles through the
+    // scalar cache as always.  What runs SAME (92-sample windows on a 92.16
+    // grid), Bell-103 (160) and RTTY (1056).
+    __device__ __forceinline__ void pass_direct( uint32_t A, uint32_t w0, uint32_t nw )
+    {
+	const uint32_t B = cfg.bit_nsamples;
+	const uint32_t w = w0 + lane;
+	const bool active = lane < nw;
+	const uint32_t a = A + win_rel(active ? w : w0);
+	const uint32_t Bpad = ( B + XCH - 1u ) & ~(uint32_t)( XCH - 1 );
+	double mr = 0.0, mi = 0.0, sr = 0.0, si = 0.0;
+	if ( __all(a + Bpad <= N && a + Bpad >= a) ) {
+	    const float *p = x + a;
+	    float4_u c0 = *reinterpret_cast<const float4_u *>(p);
+	    float4_u c1 = *reinterpret_cast<const float4_u *>(p + 4);
+	    for ( uint32_t n0 = 0; n0 < B; n0 += XCH ) {
+		float4_u d0 = c0, d1 = c1;
+		if ( n0 + XCH < B ) {		// uniform: the next chunk, in flight during this one's FMAs
+		    d0 = *reinterpret_cast<const float4_u *>(p + n0 + XCH);
+		    d1 = *reinterpret_cast<const float4_u *>(p + n0 + XCH + 4);
+		}
+		tw8 ta, tb, tc, td;
+		twiddle_fetch_ro(tw + 4 * (size_t)n0, ta, tb, tc, td);
+		twiddle_wait_ro();
+		MIFSK_FMA4(c0.x, ta, 0);  MIFSK_FMA4(c0.y, ta, 1);
+		MIFSK_FMA4(c0.z, tb, 0);  MIFSK_FMA4(c0.w, tb, 1);
+		MIFSK_FMA4(c1.x, tc, 0);  MIFSK_FMA4(c1.y, tc, 1);
+		MIFSK_FMA4(c1.z, td, 0);  MIFSK_FMA4(c1.w, td, 1);
+		c0 = d0;
+		c1 = d1;
+	    }
+	} else {
+	    // a window reaches the end of the stream: per-sample guarded reads
+	    for ( uint32_t n = 0; n < B; n++ ) {
+		const uint32_t idx = a + n;
+		const double xd = (double)( ( idx < N && idx >= a ) ? x[idx] : 0.0f );
+		const double *t = tw + 4 * (size_t)n;
+		mr = fma(xd, t[0], mr);
+		mi = fma(xd, t[1], mi);
+		sr = fma(xd, t[2], sr);
+		si = fma(xd, t[3], si);
+	    }
+	}
+	if ( active )
+	    mags[w] = make_float2(band_mag(mr, mi, cfg.magscalar), band_mag(sr, si, cfg.magscalar));
+    }
+
+    // Evaluate F lattice frames anchored at A (first-try position of frame 0).
+    __device__ __forceinline__ void lattice_block( uint32_t A, uint32_t F )
+    {
+	const uint32_t t0 = MIFSK_WCLOCK();
+	const uint32_t nb = cfg.n_bits;
+	const uint32_t W = cfg.lat_grid ? F * ( nb - 1u ) + 1u : F * nb;
+	if ( g.lat_mode == LAT_LINEAR ) {
+	    const uint32_t rw = g.round_wins;
+	    for ( uint32_t w0 = 0; w0 < W; w0 += rw ) {
+		const uint32_t nw = W - w0 < rw ? W - w0 : rw;
+		// what comes after this round if the lattice goes on
+		const uint32_t next_lo = w0 + rw < W ? A + win_rel(w0 + rw)
+						     : A + F * cfg.lock_advance;
+		round_linear(A, w0, nw, next_lo);
+	    }
+	} else {
+	    for ( uint32_t w0 = 0; w0 < W; w0 += 64u )
+		pass_direct(A, w0, W - w0 < 64u ? W - w0 : 64u);
+	    wave_lds_sync();
+	}
+	// score: lane f = frame f (fsk.c:178-446 after the magnitudes)
+	FrameOut fo;
+	fo.conf = 0.0f; fo.ampl = 0.0f; fo.bits = 0;
+	if ( lane < F ) {
+	    const uint32_t ci = cfg.lat_grid ? lane * ( nb - 1u ) : lane * nb;
+	    fo = frame_confidence_any(&mags[ci], cfg.req_mask[0], cfg.req_val[0], nb);
+	}
+	l_conf = fo.conf;
+	l_ampl = fo.ampl;
+	l_bits = fo.bits;
+	lat_n = F;
+	lat_anchor = A;
+	slab_lo = slab_hi = 0;			// the rounds overwrote whatever SCAN had staged
+	wave_lds_sync();
+	n_blocks++;
+	cyc_block += MIFSK_WCLOCK() - t0;
+    }
+
+    // ------------------------------------------------------------------
+    // SCAN: fsk_find_frame at cursor `base` (absolute).  Every candidate of the
+    // zig-zag scan and every bit of it is evaluated (one lane per bit window),
+    // then the reference's selection (strict >, first tried wins ties, early
+    // exit at the limit, fsk.c:492-501) is replayed in scan order.
+    // ------------------------------------------------------------------
+
+    // sample at absolute index i as a search at `base` sees it
+    __device__ __forceinline__ float sample_at( uint32_t base, uint32_t i ) const
+    {
+	if ( ring )
+	    return ring[i - base];		// the reference's buffer cell (always allocated)
+	return i < N ? x[i] : 0.0f;
+    }
+
+    // stage [lo, lo + n) into the skewed slab whose row 0 is sample lo
+    __device__ __forceinline__ void stage_slab( uint32_t base, uint32_t lo, uint32_t n )
+    {
+	const uint32_t org4 = lo & ~3u;
+	const uint32_t head = lo - org4;
+	const uint32_t nvec = ( n + head + 3 ) >> 2;
+	if ( ring ) {
+	    // RING addressing: cells of the device-resident samplebuf, element-wise
+	    for ( uint32_t v0 = 0; v0 < nvec; v0 += 64u ) {
+		const uint32_t v = v0 + lane;
+		if ( v < nvec ) {
+		    const uint32_t a = org4 + ( v << 2 );
+		    float4 s;
+		    s.x = a >= base ? ring[a - base] : 0.0f;
+		    s.y = a + 1 >= base ? ring[a + 1 - base] : 0.0f;
+		    s.z = a + 2 >= base ? ring[a + 2 - base] : 0.0f;
+		    s.w = a + 3 >= base ? ring[a + 3 - base] : 0.0f;
+		    store4_skewed(cfg, slab, g.slab_cap, v << 2, head, s, a, 0xFFFFFFF0u);
+		}
+	    }
+	    return;
+	}
+	for ( uint32_t v0 = 0; v0 < nvec; v0 += 64u * SV ) {
+	    float4 buf[SV];
+#pragma unroll
+	    for ( int i = 0; i < SV; i++ ) {
+		const uint32_t v = v0 + i * 64 + lane;
+		if ( v0 + i * 64 < nvec )
+		    buf[i] = load4_raw(x, org4 + ( v << 2 ), N);
+	    }
+#pragma unroll
+	    for ( int i = 0; i < SV; i++ ) {
+		const uint32_t v = v0 + i * 64 + lane;
+		if ( v0 + i * 64 < nvec && v < nvec )
+		    store4_skewed(cfg, slab, g.slab_cap, v << 2, head, buf[i], org4 + ( v << 2 ), N);
+	    }
+	}
+    }
+
+    // correlate candidates c0 .. c0+Q of `zz` at cursor base into mags[q * n_bits + k]
+    __device__ __forceinline__ void scan_correlate( uint32_t base, const ZigZag &zz, uint32_t c0,
+	    uint32_t Q, bool use_slab )
+    {
+	const uint32_t nb = cfg.n_bits, B = cfg.bit_nsamples;
+	const uint32_t nwin = Q * nb;
+	for ( uint32_t w0 = 0; w0 < nwin; w0 += 64u ) {
+	    const uint32_t w = w0 + lane;
+	    const bool active = w < nwin;
+	    const uint32_t q = active ? udiv_magic(w, nb, cfg.nbits_magic) : 0u;
+	    const uint32_t k = active ? w - q * nb : 0u;
+	    const uint32_t a = base + zz.at(c0 + q) + cfg.bit_offset[k & 63u];
+	    double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
+	    if ( use_slab ) {
+		correlate_window(cfg, tw, slab, a - slab_lo, active, acc);
+	    } else if ( !ring && __all(a + ( ( B + 7u ) & ~7u ) <= N && a + B + 8u >= a) ) {
+		// long windows (or no slab at this occupancy): stream from global
+		// memory, 32 bytes per lane per step, next chunk in flight
+		const float *p = x + a;
+		float4_u c0v = *reinterpret_cast<const float4_u *>(p);
+		float4_u c1v = *reinterpret_cast<const float4_u *>(p + 4);
+		double mr = 0.0, mi = 0.0, sr = 0.0, si = 0.0;
+		for ( uint32_t n0 = 0; n0 < B; n0 += XCH ) {
+		    float4_u d0 = c0v, d1 = c1v;
+		    if ( n0 + XCH < B ) {
+			d0 = *reinterpret_cast<const float4_u *>(p + n0 + XCH);
+			d1 = *reinterpret_cast<const float4_u *>(p + n0 + XCH + 4);
+		    }
+		    tw8 ta, tb, tc, td;
+		    twiddle_fetch_ro(tw + 4 * (size_t)n0, ta, tb, tc, td);
+		    twiddle_wait_ro();
+		    MIFSK_FMA4(c0v.x, ta, 0);  MIFSK_FMA4(c0v.y, ta, 1);
+		    MIFSK_FMA4(c0v.z, tb, 0);  MIFSK_FMA4(c0v.w, tb, 1);
+		    MIFSK_FMA4(c1v.x, tc, 0);  MIFSK_FMA4(c1v.y, tc, 1);
+		    MIFSK_FMA4(c1v.z, td, 0);  MIFSK_FMA4(c1v.w, td, 1);
+		    c0v = d0;
+		    c1v = d1;
+		}
+		acc[0] = mr; acc[1] = mi; acc[2] = sr; acc[3] = si;
+	    } else {
+		for ( uint32_t n = 0; n < B; n++ ) {
+		    const uint32_t idx = a + n;
+		    const double xd = (double)( idx >= a ? sample_at(base, idx) : 0.0f );
+		    const double *t = tw + 4 * (size_t)n;
+		    acc[0] = fma(xd, t[0], acc[0]);
+		    acc[1] = fma(xd, t[1], acc[1]);
+		    acc[2] = fma(xd, t[2], acc[2]);
+		    acc[3] = fma(xd, t[3], acc[3]);
+		}
+	    }
+	    if ( active )
+		mags[w] = make_float2(band_mag(acc[0], acc[1], cfg.magscalar),
+				      band_mag(acc[2], acc[3], cfg.magscalar));
+	}
+    }
+
+    __device__ __forceinline__ ScanResult scan( uint32_t base, const ZigZag &zz, uint32_t first,
+	    float limit, uint32_t kind, bool carrier_held )
+    {
+	ScanResult r;
+	r.conf = 0.0f; r.ampl = 0.0f; r.bits = 0; r.start = 0;
+	if ( zz.J == 0 )
+	    return r;
+	const uint32_t t0 = MIFSK_WCLOCK();
+	// the first candidate may be a lattice frame that is already scored
+	// (those are scored against the data string)
+	{
+	    const uint32_t hit = kind == 0u ? lattice_lookup(base + first) : ~0u;
+	    if ( hit != ~0u ) {
+		const float c = lane_bcast(l_conf, hit);
+		if ( c > 0.0f && c >= limit ) {			// fsk.c:492,499
+		    r.conf = c;
+		    r.ampl = lane_bcast(l_ampl, hit);
+		    const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)l_bits, (int)hit);
+		    const uint32_t bhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)( l_bits >> 32 ), (int)hit);
+		    r.bits = ( (uint64_t)bhi << 32 ) | blo;
+		    r.start = first;
+		    n_hits++;
+		    return r;
+		}
+	    }
+	}
+	const uint32_t nb = cfg.n_bits;
+	uint32_t qmax = g.mags_cap / nb;
+	if ( qmax > 64u ) qmax = 64u;
+	bool done = false;
+	for ( uint32_t c0 = 0; c0 < zz.J && !done; c0 += qmax ) {
+	    const uint32_t Q = zz.J - c0 < qmax ? zz.J - c0 : qmax;
+	    // extent of this chunk's candidates, in closed form (see ZigZag)
+	    const uint32_t iend = c0 + Q - 1u;
+	    const uint32_t lu = iend > 2u * zz.D ? iend : ( ( iend & 1u ) ? iend : iend - 1u );
+	    const uint32_t ld = ( iend < 2u * zz.D ? iend : 2u * zz.D ) & ~1u;
+	    const bool has_up = lu >= ( c0 > 1u ? c0 : 1u ) && lu <= iend && iend >= 1u;
+	    const bool has_down = ld >= 2u && ld >= c0;
+	    const uint32_t thi = has_up ? zz.at(lu) : zz.at(c0);
+	    const uint32_t tlo = has_down ? zz.at(ld) : zz.at(c0);
+	    const uint32_t lo = base + tlo, hi = base + thi + cfg.last_reach;
+	    bool use_slab = g.slab_cap != 0u && hi - lo + 8u <= g.slab_cap;
+	    if ( use_slab && ( ring || lo < slab_lo || hi > slab_hi ) ) {
+		// Without a carrier the searches that follow advance through the
+		// stream and reuse what is staged now: fill the slab.  With the
+		// carrier held the next SCAN is many frames away: stage what this
+		// search reads and no more.
+		const uint32_t need = ( hi - lo + 7u ) & ~3u;
+		const uint32_t take = ( carrier_held || ring ) ? need : g.slab_cap;
+		slab_lo = lo;
+		slab_hi = lo + take;
+		drop_prefetch();		// (the cursor left the lattice)
+		stage_slab(base, lo, take);
+		wave_lds_sync();
+		n_stages++;
+	    }
+	    scan_correlate(base, zz, c0, Q, use_slab);
+	    wave_lds_sync();
+	    FrameOut f;
+	    f.conf = 0.0f; f.ampl = 0.0f; f.bits = 0;
+	    if ( lane < Q )
+		f = frame_confidence_any(&mags[lane * nb], cfg.req_mask[kind], cfg.req_val[kind], nb);
+	    wave_lds_sync();			// mags[] is free again
+	    n_scans++;
+	    n_positions += Q;
+	    // fsk.c:492-501 over the chunk, in scan order on lane values
+	    uint32_t win = ~0u;
+	    for ( uint32_t i = 0; i < Q; i++ ) {
+		const float c = lane_bcast(f.conf, i);
+		if ( r.conf < c ) {
+		    r.conf = c;
+		    win = i;
+		    if ( r.conf >= limit ) {
+			done = true;
+			break;
+		    }
+		}
+	    }
+	    if ( win != ~0u ) {
+		r.ampl = lane_bcast(f.ampl, win);
+		const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)f.bits, (int)win);
+		const uint32_t bhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)( f.bits >> 32 ), (int)win);
+		r.bits = ( (uint64_t)bhi << 32 ) | blo;
+		r.start = zz.at(c0 + win);
+	    }
+	}
+	cyc_scan += MIFSK_WCLOCK() - t0;
+	return r;
+    }
+};
+
+// v[src lane] for a per-lane source index (ds_bpermute)
+__device__ __forceinline__ float lane_gather( float v, uint32_t src )
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((int)( src << 2 ), __builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ uint64_t lane_gather64( uint64_t v, uint32_t src )
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)( src << 2 ), (int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)( src << 2 ), (int)(uint32_t)( v >> 32 ));
+    return ( (uint64_t)hi << 32 ) | lo;
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char mifsk_wave_smem[];
+
+template <int SV>
+__global__ __launch_bounds__(64, 4)
+void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restrict__ tw_default,
+	mifsk_demod_io io, WaveGeom g, WaveAuto au )
+{
+    const DevCfg &cfg = *cfgp;
+    const uint32_t s = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const bool t0 = lane == 0;
+
+    float2 *mags = reinterpret_cast<float2 *>(mifsk_wave_smem);
+    float *slab = reinterpret_cast<float *>(mifsk_wave_smem + (size_t)g.mags_cap * sizeof(float2));
+
+    const float *x = io.d_samples + (size_t)s * io.stream_stride;
+    uint32_t N = io.d_nsamples ? io.d_nsamples[s] : io.nsamples;
+    if ( (size_t)N > io.stream_stride )
+	N = (uint32_t)io.stream_stride;		// never trust a length beyond the row
+    // How far this stream's row may be over-read (in samples from its start)
+    // without leaving the batch: the rows after it, or for the last row its own
+    // length.  The linear LATTICE fetches whole rounds with no per-lane bounds
+    // logic and needs at least one round of room.
+    const uint64_t rows_after = (uint64_t)( io.nstreams - 1 - (int)s ) * io.stream_stride;
+    uint32_t safe_limit = rows_after == 0 ? N
+			: rows_after > 0xFFFF0000ull ? 0xFFFF0000u : (uint32_t)rows_after;
+    bool lattice_ok = g.lat_mode != LAT_NONE;
+    if ( g.lat_mode == LAT_LINEAR && safe_limit < Wave<SV>::kRoundFloats ) {
+	lattice_ok = false;
+	safe_limit = Wave<SV>::kRoundFloats;
+    }
+    float *ring = g.ring_exact ? au.d_ring + (size_t)s * g.ring_stride : nullptr;
+    if ( ring )
+	lattice_ok = false;			// RING addressing: every frame through the general path
+    const double *tw = tw_default;
+    double *tw_own = nullptr;
+    if ( g.autodetect ) {
+	tw_own = au.d_tw_scratch + (size_t)s * g.tw_entries * 4u;
+	tw = tw_own;
+    }
+
+    WaveOut o;
+    o.fcap = (uint32_t)( io.frames_cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : io.frames_cap );
+    o.ecap = (uint32_t)( io.episodes_cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : io.episodes_cap );
+    o.bytes = io.d_bytes ? io.d_bytes + (size_t)s * io.frames_cap : nullptr;
+    o.bits = io.d_bits ? io.d_bits + (size_t)s * io.frames_cap : nullptr;
+    o.frames = io.d_frames ? io.d_frames + (size_t)s * io.frames_cap : nullptr;
+    o.eps = io.d_episodes ? io.d_episodes + (size_t)s * io.episodes_cap : nullptr;
+
+    Wave<SV> ctx(cfg, g, tw, x, N, mags, slab, ring, safe_limit);
+
+    // reference loop state (minimodem.c:1079-1088,1132-1133), uniform in the wave
+    bool carrier = false;
+    float confidence_total = 0.0f, amplitude_total = 0.0f;
+    uint32_t nframes_decoded = 0;
+    uint64_t carrier_nsamples = 0;
+    uint32_t noconfidence = 0;
+    uint32_t advance = 0;
+    float track_amplitude = 0.0f, peak_confidence = 0.0f;
+    // (base, rp): absolute index of samplebuf[0], and the file position;
+    // samples_nvalid = rp - base
+    uint32_t base = 0, rp = 0;
+    const uint32_t bufsize = g.bufsize, half = g.bufsize / 2u;
+    // --auto-carrier
+    int carrier_band = -1;				// `static int carrier_band = -1`
+    int first_band = -1;
+    uint32_t b_mark = cfg.b_mark;
+
+    uint32_t n_out_frames = 0, n_out_bytes = 0, n_out_eps = 0, ep_first = 0, ep_b_mark = 0;
+    uint32_t status = 0;
+    uint32_t n_iter = 0, n_bulk = 0, n_refine = 0, n_detect = 0;
+    const uint32_t t_start = MIFSK_WCLOCK();
+
+    const ZigZag zc0(cfg.try_first[0], cfg.try_max[0], cfg.try_step[0]);
+    const ZigZag zc1(cfg.try_first[1], cfg.try_max[1], cfg.try_step[1]);
+    const ZigZag zf0(cfg.try_first[0], cfg.try_max[0], cfg.try_step_fine[0]);
+    const ZigZag zf1(cfg.try_first[1], cfg.try_max[1], cfg.try_step_fine[1]);
+    const uint32_t la = cfg.lock_advance;
+
+    // every pass through the loop moves the cursor forward (or ends the loop):
+    // a bound far above anything reachable turns a logic error into a flagged
+    // stream instead of a hung GPU
+    uint32_t guard = 0;
+    const uint32_t guard_max = 2u * N + 1024u;
+    for (;;) {
+	if ( ++guard > guard_max ) {
+	    status |= MIFSK_STREAM_ABORTED;
+	    break;
+	}
+	// ------------------------------------------------------------------
+	// Bulk acceptance of lattice frames.  While carrier is held and the
+	// cursor lands on the lattice, the reference's iteration for frame k
+	// reduces to: first try wins the coarse scan (c >= limit), no refine
+	// (c >= 0.75 peak), no squelch (a >= 0.25 track, c > threshold).  Those
+	// predicates and the f32 state recurrences are replayed here in frame
+	// order from the scored (confidence, amplitude) pairs; the first frame
+	// that fails any of them falls through to the general path below.
+	// (Every frame accepted here lies wholly inside the stream, where
+	// samples_nvalid >= half the buffer >= everything a search reads: the
+	// launcher enables the lattice only for such geometries.)
+	// ------------------------------------------------------------------
+	if ( lattice_ok && carrier && advance && advance <= N - base ) {
+	    const uint32_t first = cfg.try_first[1];
+	    const uint32_t nb = base + advance;		// cursor of the next iteration
+	    const uint32_t p = nb + first;
+	    uint32_t e0 = ctx.lattice_lookup(p);
+	    // frames from cursor nb on that still see expect_nsamples (minimodem.c:1229)
+	    const uint32_t room = N - nb >= cfg.expect_nsamples
+				? udiv_magic(N - nb - cfg.expect_nsamples, la, cfg.la_magic) + 1u : 0u;
+	    if ( e0 == ~0u && room && !ctx.pause ) {
+		uint32_t F = ctx.spec < room ? ctx.spec : room;
+		ctx.lattice_block(p, F);
+		e0 = 0;
+	    }
+	    bool progressed = false;
+	    if ( e0 != ~0u ) {
+		uint32_t K = ctx.lat_n - e0;
+		K = K < room ? K : room;
+		// this lane's candidate (lane k <-> entry e0 + k)
+		const bool have = lane < K;
+		float cv, av;
+		if ( e0 == 0u ) {
+		    cv = ctx.l_conf;
+		    av = ctx.l_ampl;
+		} else {
+		    cv = lane_gather(ctx.l_conf, e0 + lane);
+		    av = lane_gather(ctx.l_ampl, e0 + lane);
+		}
+		cv = have ? cv : 0.0f;
+		av = have ? av : 0.0f;
+		// Replay the f32 state recurrences over all K candidates as a lane
+		// scan (replay_scan_asm): lane k computes the state AFTER frame k by
+		// applying the reference's update to its lower neighbour's state.
+		float xt = ( track_amplitude + av ) / 2.0f;		// minimodem.c:1391
+		float xpk = peak_confidence < cv ? cv : peak_confidence;	// :1392-1393
+		float xsc = confidence_total + cv;			// :1397-1398
+		float xsa = amplitude_total + av;
+		float my_t = track_amplitude, my_pk = peak_confidence;
+		float my_sc = confidence_total, my_sa = amplitude_total;
+		replay_scan_asm(xt, xpk, xsc, xsa, my_t, my_pk, my_sc, my_sa, cv, av, K);
+		const bool ok = have
+		    && cv > 0.0f && cv >= cfg.search_limit	// fsk.c:492,499: first try ends the scan
+		    && !( cv < my_pk * 0.75f )			// minimodem.c:1278
+		    && !( av < my_t * 0.25f )			// minimodem.c:1286
+		    && !( cv <= cfg.conf_threshold );		// minimodem.c:1292
+		const unsigned long long bad = __ballot(have && !ok);
+		const uint32_t n = bad ? (uint32_t)__ffsll((long long)bad) - 1u : K;
+		ctx.run += n;
+		if ( n < K ) {			// the lattice broke here: remember how long it held
+		    ctx.spec = ctx.run < g.lat_fmin ? g.lat_fmin
+			     : ( ctx.run < g.lat_fmax ? ctx.run : g.lat_fmax );
+		    ctx.cold = ctx.run ? 0u : ctx.cold + 1u;
+		    ctx.run = 0;
+		    if ( ctx.cold >= 4u ) {	// it keeps missing: plain searches for a while
+			ctx.cold = 0;
+			ctx.pause = 32;
+		    }
+		} else if ( e0 + K == ctx.lat_n ) {	// a whole block held: speculate further
+		    ctx.spec = 2u * ctx.spec < g.lat_fmax ? 2u * ctx.spec : g.lat_fmax;
+		}
+		if ( n ) {
+		    float track, peak, ctot, atot;
+		    if ( n == K ) {
+			track = lane_bcast(xt, K - 1u);
+			peak = lane_bcast(xpk, K - 1u);
+			ctot = lane_bcast(xsc, K - 1u);
+			atot = lane_bcast(xsa, K - 1u);
+		    } else {
+			track = lane_bcast(my_t, n);
+			peak = lane_bcast(my_pk, n);
+			ctot = lane_bcast(my_sc, n);
+			atot = lane_bcast(my_sa, n);
+		    }
+		    // outputs of frames 0..n-1, one lane each
+		    const bool mine = lane < n;
+		    const uint64_t fb = e0 == 0u ? ctx.l_bits : lane_gather64(ctx.l_bits, e0 + lane);
+		    uint64_t db = 0;
+		    bool suppressed = false;
+		    if ( mine ) {
+			db = data_bits_of(cfg, fb);
+			suppressed = cfg.do_rx_sync && db == cfg.sync_byte;
+		    }
+		    const unsigned long long keep = __ballot(mine && !suppressed);
+		    if ( mine ) {
+			const uint32_t fi = n_out_frames + lane;
+			if ( fi < o.fcap ) {
+			    if ( o.bits )
+				o.bits[fi] = db;
+			    if ( o.frames ) {
+				mifsk_frame f;
+				f.bits = db;
+				f.start = (uint64_t)nb + (uint64_t)lane * la + first;
+				f.confidence = cv;
+				f.amplitude = av;
+				f.flags = suppressed ? MIFSK_FRAME_SYNC : 0u;
+				f.reserved = 0;
+				o.frames[fi] = f;
+			    }
+			}
+			if ( !suppressed && o.bytes ) {
+			    const uint32_t bi = n_out_bytes
+				+ (uint32_t)__popcll(keep & ( ( 1ULL << lane ) - 1ULL ));
+			    if ( bi < o.fcap )
+				o.bytes[bi] = (uint8_t)( db & 0xFFu );
+			}
+		    }
+		    n_out_frames += n;
+		    n_out_bytes += (uint32_t)__popcll(keep);
+		    // state after n trivially accepted frames: each advanced the
+		    // cursor by lock_advance = first + fn - overscan and added
+		    // fn + first - overscan to carrier_nsamples (minimodem.c:1324-1330,1407)
+		    track_amplitude = track;
+		    peak_confidence = peak;
+		    confidence_total = ctot;
+		    amplitude_total = atot;
+		    nframes_decoded += n;
+		    noconfidence = 0;
+		    carrier_nsamples += (uint64_t)n * ( cfg.frame_nsamples + first - cfg.overscan );
+		    base = nb + ( n - 1u ) * la;
+		    advance = la;
+		    // the half-buffer refills those n iterations made (minimodem.c:1158-1174)
+		    // (one refill per iteration whenever fewer than half a buffer is
+		    // valid: after n iterations the file position is the first
+		    // rp + m * half that leaves at least half a buffer beyond the cursor)
+		    while ( rp < base + half && rp < N )
+			rp += N - rp < half ? N - rp : half;
+		    n_bulk += n;
+		    progressed = true;
+		}
+	    }
+	    if ( progressed )
+		continue;
+	}
+
+	// ------------------------------------------------------------------
+	// one iteration of the reference's loop
+	// ------------------------------------------------------------------
+	if ( advance == bufsize ) {				// minimodem.c:1146-1149: samples_nvalid = 0
+	    base += advance;
+	    rp = base;
+	    advance = 0;
+	}
+	if ( base > rp )
+	    break;						// (cannot happen: samples_nvalid >= 0)
+	if ( advance ) {					// :1150-1156
+	    if ( advance > rp - base )
+		break;
+	    if ( ring ) {
+		// memmove(samplebuf, samplebuf + advance, (size - advance) floats):
+		// ascending 64-cell chunks, each read before it is written
+		// (a cell is never read after it has been written: reads run `advance`
+		// cells ahead of the writes; one fence at the end publishes the lot)
+		const uint32_t cnt = bufsize - advance;
+		for ( uint32_t j = 0; j < cnt; j += 64u ) {
+		    const uint32_t c = j + lane;
+		    if ( c < cnt )
+			ring[c] = ring[c + advance];
+		}
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+	    }
+	    base += advance;
+	    advance = 0;
+	}
+	if ( rp - base < half ) {				// :1158-1174
+	    const uint32_t r = N - rp < half ? N - rp : half;
+	    if ( ring ) {
+		const uint32_t nv = rp - base;
+		for ( uint32_t j = lane; j < r; j += 64u )
+		    ring[nv + j] = x[rp + j];
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+	    }
+	    rp += r;
+	}
+	const uint32_t nvalid = rp - base;
+	if ( nvalid == 0 )					// :1176
+	    break;
+
+	if ( g.autodetect && carrier_band < 0 ) {		// :1179-1220
+	    uint32_t i = 0;
+	    const float nps = g.nps;
+	    int band = -1;
+	    while ( (float)i + nps <= (float)nvalid ) {		// float arithmetic, as there
+		band = wave_detect_window(x + base + i, (uint32_t)nps, au.d_cs, g.fftsize, g.nbands,
+					  g.auto_threshold);
+		n_detect++;
+		if ( band >= 0 )
+		    break;
+		i = (uint32_t)( (float)i + nps );
+	    }
+	    advance = (uint32_t)( (float)i + nps );		// :1193-1195
+	    if ( advance > nvalid )
+		advance = nvalid;
+	    if ( band < 0 )
+		continue;
+	    const int b_space = band + g.b_shift;		// :1203-1213
+	    if ( b_space < 1 || b_space >= (int)g.nbands )
+		continue;
+	    carrier_band = band;
+	    // fsk_set_tones_by_bandshift (fsk.c:584-598): this stream's own table
+	    // tw[4 n + {0,1,2,3}] = cos, -sin of 2 pi ((b n) mod N) / N for mark, space
+	    b_mark = (uint32_t)band;
+	    if ( first_band < 0 )
+		first_band = band;
+	    for ( uint32_t n = lane; n < g.tw_entries; n += 64u ) {
+		double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0;
+		if ( n < cfg.bit_nsamples ) {
+		    const uint32_t km = ( (uint32_t)band * n ) % g.fftsize;
+		    const uint32_t ks = ( (uint32_t)b_space * n ) % g.fftsize;
+		    w0 = au.d_cs[2 * (size_t)km];
+		    w1 = au.d_cs[2 * (size_t)km + 1];
+		    w2 = au.d_cs[2 * (size_t)ks];
+		    w3 = au.d_cs[2 * (size_t)ks + 1];
+		}
+		double *t = tw_own + 4 * (size_t)n;
+		t[0] = w0; t[1] = w1; t[2] = w2; t[3] = w3;
+	    }
+	    // the table is read back through the scalar cache (and by vector loads
+	    // in the tail paths): complete the stores, then drop stale lines
+	    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+	    __builtin_amdgcn_s_dcache_inv();
+	    ctx.lat_n = 0;				// scored with the old tones
+	    ctx.slab_lo = ctx.slab_hi = 0;
+	}
+
+	if ( nvalid < cfg.expect_nsamples )			// :1229
+	    break;
+	n_iter++;
+
+	const uint32_t ci = carrier ? 1u : 0u;
+	const uint32_t try_max = cfg.try_max[ci];
+	const uint32_t try_step = cfg.try_step[ci];
+	const uint32_t try_first = cfg.try_first[ci];
+
+	ScanResult sr = ctx.scan(base, carrier ? zc1 : zc0, try_first, cfg.search_limit,
+				 carrier ? 0u : 1u, carrier);	// minimodem.c:1265-1274
+	float confidence = sr.conf;
+	float amplitude = sr.ampl;
+	uint64_t bits = sr.bits;
+	uint32_t frame_start = sr.start;
+
+	bool refine = false;
+	if ( confidence < peak_confidence * 0.75f ) {		// minimodem.c:1278-1282
+	    refine = true;
+	    peak_confidence = 0.0f;
+	}
+	if ( amplitude < track_amplitude * 0.25f )		// minimodem.c:1286-1288
+	    confidence = 0.0f;
+
+	if ( confidence <= cfg.conf_threshold ) {		// minimodem.c:1292-1321
+	    if ( ++noconfidence > 20u ) {
+		carrier_band = -1;				// :1297
+		if ( carrier ) {
+		    if ( t0 && o.eps && n_out_eps < o.ecap ) {
+			mifsk_episode e;
+			e.carrier_nsamples = carrier_nsamples;
+			e.first_frame = ep_first;
+			e.nframes = nframes_decoded;
+			e.confidence_total = confidence_total;
+			e.amplitude_total = amplitude_total;
+			e.end_reason = 1;
+			e.b_mark = ep_b_mark;
+			o.eps[n_out_eps] = e;
+		    }
+		    n_out_eps++;
+		    carrier = false;
+		    carrier_nsamples = 0;
+		    confidence_total = 0.0f;
+		    amplitude_total = 0.0f;
+		    nframes_decoded = 0;
+		    track_amplitude = 0.0f;
+		    if ( cfg.rx_one )
+			break;
+		}
+	    }
+	    advance = try_max;
+	    continue;
+	}
+
+	carrier_nsamples += cfg.frame_nsamples;			// minimodem.c:1324
+	uint32_t flags = 0;
+	if ( carrier ) {
+	    carrier_nsamples += frame_start;			// minimodem.c:1329-1330
+	    carrier_nsamples -= cfg.overscan;
+	} else {
+	    carrier = true;					// minimodem.c:1350-1353
+	    refine = true;
+	    flags |= MIFSK_FRAME_ACQUIRE;
+	    ep_first = n_out_frames;
+	    ep_b_mark = b_mark;					// :1340,1344
+	}
+
+	if ( refine && confidence < INFINITY && try_step > 1u ) {	// minimodem.c:1357-1389
+	    // `carrier` is already set: an acquiring frame is re-searched with
+	    // the data string over the no-carrier range (minimodem.c:1378)
+	    ScanResult s2 = ctx.scan(base, ci ? zf1 : zf0, try_first, INFINITY, 0u, true);
+	    flags |= MIFSK_FRAME_REFINED;
+	    n_refine++;
+	    if ( s2.conf > confidence ) {
+		bits = s2.bits;
+		amplitude = s2.ampl;
+		frame_start = s2.start;
+	    }
+	}
+
+	track_amplitude = ( track_amplitude + amplitude ) / 2.0f;	// minimodem.c:1391-1400
+	if ( peak_confidence < confidence )
+	    peak_confidence = confidence;
+	confidence_total += confidence;
+	amplitude_total += amplitude;
+	nframes_decoded++;
+	noconfidence = 0;
+
+	advance = frame_start + cfg.frame_nsamples - cfg.overscan;	// minimodem.c:1407
+
+	bits = data_bits_of(cfg, bits);					// minimodem.c:1415-1428
+	const bool suppressed = cfg.do_rx_sync && bits == cfg.sync_byte;	// minimodem.c:1436-1439
+	if ( suppressed )
+	    flags |= MIFSK_FRAME_SYNC;
+
+	if ( t0 ) {
+	    if ( n_out_frames < o.fcap ) {
+		if ( o.bits )
+		    o.bits[n_out_frames] = bits;
+		if ( o.frames ) {
+		    mifsk_frame f;
+		    f.bits = bits;
+		    f.start = (uint64_t)base + frame_start;
+		    f.confidence = confidence;
+		    f.amplitude = amplitude;
+		    f.flags = flags;
+		    f.reserved = 0;
+		    o.frames[n_out_frames] = f;
+		}
+	    }
+	    if ( !suppressed && o.bytes && n_out_bytes < o.fcap )
+		o.bytes[n_out_bytes] = (uint8_t)( bits & 0xFFu );
+	}
+	n_out_frames++;
+	if ( !suppressed )
+	    n_out_bytes++;
+	if ( ctx.pause )
+	    ctx.pause--;
+    }
+
+    if ( carrier ) {						// minimodem.c:1469-1474
+	if ( t0 && o.eps && n_out_eps < o.ecap ) {
+	    mifsk_episode e;
+	    e.carrier_nsamples = carrier_nsamples;
+	    e.first_frame = ep_first;
+	    e.nframes = nframes_decoded;
+	    e.confidence_total = confidence_total;
+	    e.amplitude_total = amplitude_total;
+	    e.end_reason = 2;
+	    e.b_mark = ep_b_mark;
+	    o.eps[n_out_eps] = e;
+	}
+	n_out_eps++;
+    }
+    if ( t0 ) {
+	if ( n_out_frames > o.fcap && ( o.bits || o.frames || o.bytes ) )
+	    status |= MIFSK_STREAM_FRAMES_TRUNCATED;
+	if ( n_out_eps > o.ecap && o.eps )
+	    status |= MIFSK_STREAM_EPISODES_TRUNCATED;
+	if ( io.d_nframes ) io.d_nframes[s] = n_out_frames;
+	if ( io.d_nbytes ) io.d_nbytes[s] = n_out_bytes;
+	if ( io.d_nepisodes ) io.d_nepisodes[s] = n_out_eps;
+	if ( io.d_status ) io.d_status[s] = status;
+	if ( io.d_carrier_band && g.autodetect ) io.d_carrier_band[s] = first_band;
+	if ( io.d_counters ) {
+	    uint64_t *c = io.d_counters + (size_t)s * MIFSK_NCOUNTERS;
+	    for ( int i = 0; i < MIFSK_NCOUNTERS; i++ )
+		c[i] = 0;
+	    c[MIFSK_CNT_ITERATIONS] = n_iter;
+	    c[MIFSK_CNT_BATCHES] = ctx.n_scans;
+	    c[MIFSK_CNT_STAGES] = ctx.n_stages;
+	    c[MIFSK_CNT_BULK_FRAMES] = n_bulk;
+	    c[MIFSK_CNT_REFINES] = n_refine;
+	    c[MIFSK_CNT_CACHE_HITS] = ctx.n_hits;
+	    c[MIFSK_CNT_POSITIONS] = ctx.n_positions;
+	    c[MIFSK_CNT_LATTICE_BATCHES] = ctx.n_blocks;
+	    c[MIFSK_CNT_CYC_TOTAL] = MIFSK_WCLOCK() - t_start;
+	    c[MIFSK_CNT_CYC_PARALLEL] = ctx.cyc_scan;
+	    c[MIFSK_CNT_CYC_WAIT] = ctx.cyc_block;
+	    c[22] = n_detect;
+	}
+    }
+}
+
+// ---------------------------------------------------------------------------
+// launcher: occupancy and LDS geometry per configuration
+// ---------------------------------------------------------------------------
+
+static constexpr size_t kLdsPerCu = 160 * 1024;
+
+namespace {
+
+struct Plan {
+    WaveGeom	g;
+    int		sv;		// staging width of the kernel instantiation
+    size_t	lds_bytes;
+};
+
+// windows of the first F frames of a block
+inline uint32_t wins_of( const DevCfg &cfg, uint32_t F )
+{
+    return cfg.lat_grid ? F * ( cfg.n_bits - 1u ) + 1u : F * cfg.n_bits;
+}
+inline uint32_t rel_of( const DevCfg &cfg, uint32_t w )
+{
+    return cfg.lat_grid ? w * cfg.bit_nsamples
+			: ( w / cfg.n_bits ) * cfg.lock_advance + cfg.bit_offset[w % cfg.n_bits];
+}
+
+// Geometry for a staging width `sv` within `budget` bytes of LDS per wave;
+// false when it does not fit.
+bool plan_for( const DevCfg &cfg, const WaveHostArgs &ha, int sv, size_t budget, Plan &out )
+{
+    const uint32_t B = cfg.bit_nsamples, nb = cfg.n_bits;
+    WaveGeom g;
+    std::memset(&g, 0, sizeof(g));
+    const uint32_t round_floats = 64u * (uint32_t)sv * 4u;
+
+    // The bulk path accepts a frame without looking at samples_nvalid: sound
+    // when half the reference's buffer (what is always valid away from the end
+    // of the stream) covers everything a carrier-held search reads and the
+    // largest advance.
+    const uint32_t half = ha.samplebuf_size / 2u;
+    const bool lattice_sound = !ha.ring_exact
+	&& half >= cfg.try_max[1] + cfg.last_reach
+	&& half >= cfg.expect_nsamples + cfg.try_max[1]
+	&& half > cfg.try_max[1] + cfg.frame_nsamples;
+    g.lat_mode = lattice_sound ? LAT_DIRECT : LAT_NONE;
+    g.lat_fmax = 64u;
+    {
+	uint32_t fmin = cfg.lat_grid ? 63u / ( nb - 1u ) : 64u / nb;	// one pass of lanes
+	if ( fmin < 2u ) fmin = 2u;
+	g.lat_fmin = fmin;
+    }
+    // LINEAR: window starts non-decreasing in window order and a round's span
+    // within one staging pass
+    if ( g.lat_mode != LAT_NONE && cfg.lat_linear ) {
+	bool ordered = true;
+	const uint32_t wtot = wins_of(cfg, 64u);
+	for ( uint32_t w = 1; w < wtot; w++ )
+	    ordered = ordered && rel_of(cfg, w) >= rel_of(cfg, w - 1);
+	uint32_t rw = 0;
+	for ( uint32_t cand = 64u; ordered && cand <= 1024u; cand += 64u ) {
+	    bool fits = true;
+	    for ( uint32_t w0 = 0; w0 < wtot && fits; w0 += cand ) {
+		const uint32_t w1 = w0 + cand < wtot ? w0 + cand : wtot;
+		fits = rel_of(cfg, w1 - 1) + B - rel_of(cfg, w0) <= round_floats;
+	    }
+	    if ( !fits )
+		break;
+	    rw = cand;
+	}
+	if ( rw ) {
+	    g.lat_mode = LAT_LINEAR;
+	    g.round_wins = rw;
+	}
+    }
+
+    // samples one search must see at once (+ slack for the chunked correlator)
+    const uint32_t reach = ( cfg.try_max[0] > cfg.try_max[1] ? cfg.try_max[0] : cfg.try_max[1] )
+			 + cfg.last_reach + 8u;
+    auto skewed_floats = [&]( uint32_t nsamp ) -> size_t {
+	return ( (size_t)nsamp + (size_t)( nsamp / B + 2 ) * cfg.skew + 8 + 3 ) & ~(size_t)3;
+    };
+    uint32_t slab_cap = ( reach + 4u + 3u ) & ~3u;
+    size_t scan_floats = skewed_floats(slab_cap);
+    const size_t region_floats = g.lat_mode == LAT_LINEAR ? round_floats + 16u : 0u;
+
+    for (;;) {
+	// a SCAN chunk scores mags_cap / n_bits candidates at once: room for a
+	// whole fine scan (<= 2 * 8 candidates) where it fits
+	uint32_t mcap = g.lat_mode != LAT_NONE ? wins_of(cfg, g.lat_fmax) : 0u;
+	if ( mcap < 16u * nb ) mcap = 16u * nb;
+	g.mags_cap = ( mcap + 1u ) & ~1u;
+	const size_t sf = scan_floats > region_floats ? scan_floats : region_floats;
+	const size_t total = (size_t)g.mags_cap * sizeof(float2) + sf * 4u + 16u;
+	if ( total <= budget ) {
+	    g.slab_floats = (uint32_t)sf;
+	    g.slab_cap = 0;
+	    if ( scan_floats ) {
+		// the skewed slab may use the whole region
+		size_t ns = sf * B / ( B + cfg.skew );
+		ns = ns > 16 ? ns - 16 : 0;
+		g.slab_cap = (uint32_t)( ns & ~(size_t)3 );
+		if ( g.slab_cap < slab_cap )
+		    g.slab_cap = slab_cap;
+	    }
+	    out.g = g;
+	    out.sv = sv;
+	    out.lds_bytes = total;
+	    return true;
+	}
+	if ( g.lat_mode != LAT_NONE && g.lat_fmax / 2u >= g.lat_fmin && g.lat_fmax > 8u ) {
+	    g.lat_fmax /= 2u;			// shorter blocks: fewer magnitude slots
+	    continue;
+	}
+	if ( scan_floats > region_floats ) {
+	    scan_floats = 0;			// SCAN streams its windows from global memory
+	    continue;
+	}
+	return false;
+    }
+}
+
+} // namespace
+
+int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_tw,
+	const mifsk_demod_io &io, const WaveHostArgs &ha, void *stream )
+{
+    if ( io.nstreams <= 0 )
+	return 0;
+    int ncu = 256;
+    {
+	int dev = 0;
+	hipDeviceProp_t prop;
+	if ( hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess
+		&& prop.multiProcessorCount > 0 )
+	    ncu = prop.multiProcessorCount;
+    }
+    // Waves per CU the batch can use (a wave is a workgroup): at least one per
+    // SIMD, at most 16 (4 per SIMD at <= 128 VGPRs).  Each gets that share of
+    // the CU's LDS; prefer the widest staging that fits, then fewer waves.
+    uint32_t want = ( (uint32_t)io.nstreams + (uint32_t)ncu - 1u ) / (uint32_t)ncu;
+    if ( want < 4u ) want = 4u;
+    if ( want > 16u ) want = 16u;
+    Plan plan;
+    bool ok = false;
+    for ( uint32_t wpc = want; wpc >= 4u && !ok; wpc -= ( wpc > 8u ? 4u : ( wpc > 4u ? 2u : 1u ) ) ) {
+	const size_t budget = ( kLdsPerCu / wpc ) & ~(size_t)255;
+	ok = plan_for(cfg, ha, 10, budget, plan) && plan.g.slab_cap != 0u;
+	if ( !ok )
+	    ok = plan_for(cfg, ha, 4, budget, plan) && plan.g.slab_cap != 0u;
+	if ( wpc == 4u )
+	    break;
+    }
+    if ( !ok ) {
+	// nothing keeps the SCAN slab in LDS (0.5 baud: 96000-sample windows):
+	// stream from global memory
+	const size_t budget = ( kLdsPerCu / want ) & ~(size_t)255;
+	ok = plan_for(cfg, ha, 4, budget, plan);
+	if ( !ok )
+	    return -12;
+    }
+    WaveGeom &g = plan.g;
+    g.bufsize = ha.samplebuf_size;
+    g.ring_exact = ha.ring_exact ? 1u : 0u;
+    g.ring_stride = ha.ring_stride;
+    g.autodetect = ha.autodetect ? 1u : 0u;
+    g.auto_threshold = ha.auto_threshold;
+    g.nps = ha.nps;
+    g.b_shift = ha.b_shift;
+    g.fftsize = ha.fftsize;
+    g.nbands = ha.nbands;
+    g.tw_entries = ha.tw_entries;
+    WaveAuto au;
+    au.d_cs = ha.d_cs;
+    au.d_tw_scratch = ha.d_tw_scratch;
+    au.d_ring = ha.d_ring;
+
+    hipStream_t st = (hipStream_t)stream;
+    const void *fn = plan.sv == 10 ? reinterpret_cast<const void *>(&demod_wave_kernel<10>)
+				   : reinterpret_cast<const void *>(&demod_wave_kernel<4>);
+    if ( hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes) != hipSuccess )
+	return -5;
+    if ( plan.sv == 10 )
+	hipLaunchKernelGGL(demod_wave_kernel<10>, dim3((unsigned)io.nstreams), dim3(64), plan.lds_bytes, st,
+			   d_cfg, d_tw, io, g, au);
+    else
+	hipLaunchKernelGGL(demod_wave_kernel<4>, dim3((unsigned)io.nstreams), dim3(64), plan.lds_bytes, st,
+			   d_cfg, d_tw, io, g, au);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+} // namespace mifsk
