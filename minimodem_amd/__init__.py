@@ -143,8 +143,8 @@ def demod_batch(ctx, cfg, samples, nsamples=None, want=("bytes", "episodes"),
     assert samples.stride(1) == 1
     nstreams, width = samples.shape
     _check_nsamples(torch, nsamples, nstreams)     # (the kernels clamp lengths to the row width)
-
-    stride = samples.stride(0)
+    # (a lone row's stride is arbitrary in torch: numpy's x[None, :] has stride 0)
+    stride = samples.stride(0) if nstreams > 1 else (int(width) + 3) & ~3
     n_uniform = int(width)
     if frames_cap is None:
         frames_cap = max_frames(cfg, n_uniform)

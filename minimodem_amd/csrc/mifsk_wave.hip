@@ -583,7 +583,7 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 
     const float *x = io.d_samples + (size_t)s * io.stream_stride;
     uint32_t N = io.d_nsamples ? io.d_nsamples[s] : io.nsamples;
-    if ( (size_t)N > io.stream_stride )
+    if ( io.nstreams > 1 && (size_t)N > io.stream_stride )
 	N = (uint32_t)io.stream_stride;		// never trust a length beyond the row
     // How far this stream's row may be over-read (in samples from its start)
     // without leaving the batch: the rows after it, or for the last row its own
