@@ -224,10 +224,10 @@ static int get_twiddles( mifsk_ctx *ctx, const TwKey &key, const double **d_out 
 	    *d_out = e.d_tw;
 	    return 0;
 	}
-    // zero-padded to a multiple of 8 samples: the correlator consumes the
-    // table in chunks of 8 and fma(x, 0, acc) leaves acc unchanged; 8 more
-    // because the software-pipelined loop fetches one half chunk ahead
-    const size_t n = ( ( (size_t)key.bit_nsamples + 7 ) & ~(size_t)7 ) + 8;
+    // zero-padded: the workgroup kernel consumes the table in chunks of 8 (and
+    // fetches one half chunk ahead), the wavefront kernel in groups of 16 (one
+    // group ahead, and keeps groups 0..2 resident): mifsk_tw_entries()
+    const size_t n = mifsk::tw_entries(key.bit_nsamples);
     std::vector<double> h(4 * ( n ? n : 8 ), 0.0);
     for ( unsigned i = 0; i < key.bit_nsamples; i++ ) {
 	twiddle(key.b_mark, i, key.fftsize, &h[4 * (size_t)i]);
@@ -401,7 +401,7 @@ static int demod_batch_wave( mifsk_ctx *ctx, const mifsk_rx_config *cfg, const D
     ha.samplebuf_size = cfg->samplebuf_size;
     ha.fftsize = (uint32_t)cfg->fftsize;
     ha.nbands = cfg->nbands;
-    ha.tw_entries = (uint32_t)( ( ( (size_t)cfg->bit_nsamples + 7 ) & ~(size_t)7 ) + 8 );
+    ha.tw_entries = (uint32_t)mifsk::tw_entries(cfg->bit_nsamples);
     void *scratch_tw = nullptr, *scratch_ring = nullptr;
     if ( cfg->auto_carrier_threshold > 0.0f ) {
 	// default negative shift, in the reference's float arithmetic (minimodem.c:1203-1206)

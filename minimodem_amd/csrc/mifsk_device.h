@@ -53,6 +53,14 @@ struct DevCfg {
 
 void fill_devcfg( DevCfg &d, const mifsk_rx_config &c );
 
+// entries (samples) of a twiddle table for bit windows of B samples: whole
+// groups of 16 plus one group of look-ahead, never fewer than three groups
+inline size_t tw_entries( unsigned B )
+{
+    const size_t n = ( ( (size_t)B + 15 ) & ~(size_t)15 ) + 16;
+    return n < 48 ? 48 : n;
+}
+
 // launchers (mifsk_kernels.hip); `stream` is a hipStream_t
 int launch_find_frame_batch( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_tw,
 	const float *d_samples, const mifsk_search *d_problems,

@@ -717,4 +717,228 @@ __device__ __forceinline__ void twiddle_wait_ro()
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// ---------------------------------------------------------------------------
+// Correlators with the twiddles in VECTOR registers (mifsk_wave.hip).
+//
+// One lane = one bit window, so at any step every lane needs the SAME twiddle
+// w[n].  Instead of streaming the table through the scalar cache (s_load into
+// 64 SGPRs, one wait per half chunk -- exposed when a SIMD runs a single wave),
+// the table is spread over the lanes: a "group" holds entries 16g .. 16g+15,
+// entry (lane & 15) in each lane, identical in the four 16-lane rows.  gfx950's
+// DPP64 form
+//     v_fmac_f64_dpp acc, w, x  row_newbcast:J
+// computes acc += w[lane J of this lane's row] * x in one instruction
+// (tools/ubench/dpp_fmac.hip checks it bit for bit against fma(__shfl(w, ..))
+// and measures 1.08-1.12 x the issue time of a plain v_fmac_f64).  No scalar
+// loads, no SGPRs, nothing to wait for: sample n costs one convert and four of
+// these, in index order -- the oracle's sums in the oracle's order.
+// Every lane of the wave must be active (a broadcast from a disabled lane
+// writes nothing): idle lanes shadow a real window.
+// ---------------------------------------------------------------------------
+
+struct TwGroup {
+    double	w[4];		// cos_mark, -sin_mark, cos_space, -sin_space of entry 16 g + (lane & 15)
+};
+
+typedef double double2_a16 __attribute__((ext_vector_type(2)));
+
+// group g of the table (zero-padded to whole groups plus one)
+__device__ __forceinline__ TwGroup tw_group_load( const double *__restrict__ tw, uint32_t g, uint32_t lane )
+{
+    const double *t = tw + 4 * (size_t)( 16u * g + ( lane & 15u ) );
+    const double2_a16 a = *reinterpret_cast<const double2_a16 *>(t);
+    const double2_a16 b = *reinterpret_cast<const double2_a16 *>(t + 2);
+    TwGroup G;
+    G.w[0] = a.x; G.w[1] = a.y; G.w[2] = b.x; G.w[3] = b.y;
+    return G;
+}
+
+template <int J>
+__device__ __forceinline__ void fmac_bcast( double &acc, const double &w, double xd )
+{
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+	: "+v"(acc) : "v"(w), "v"(xd), "i"(J));
+}
+
+// DPP reads EXEC and its source VGPR without the interlocks ordinary VALU
+// operands have, and the compiler does not know these asm statements are DPP:
+// pad once before a run of them (5 wait states after an EXEC write by SALU, 2
+// after a VALU write of the broadcast register)
+__device__ __forceinline__ void dpp_settle()
+{
+    asm volatile("s_nop 4");
+}
+
+template <int J>
+__device__ __forceinline__ void fma4_bcast( double (&acc)[4], const TwGroup &G, float x )
+{
+    const double xd = (double)x;
+    fmac_bcast<J>(acc[0], G.w[0], xd);
+    fmac_bcast<J>(acc[1], G.w[1], xd);
+    fmac_bcast<J>(acc[2], G.w[2], xd);
+    fmac_bcast<J>(acc[3], G.w[3], xd);
+}
+
+// four consecutive samples at rows J0 .. J0+3 of group G
+template <int J0>
+__device__ __forceinline__ void quad_bcast( double (&acc)[4], const TwGroup &G, const float4 &s )
+{
+    fma4_bcast<J0>(acc, G, s.x);
+    fma4_bcast<J0 + 1>(acc, G, s.y);
+    fma4_bcast<J0 + 2>(acc, G, s.z);
+    fma4_bcast<J0 + 3>(acc, G, s.w);
+}
+
+// a whole group: 16 samples
+__device__ __forceinline__ void group_bcast( double (&acc)[4], const TwGroup &G,
+	const float4 &s0, const float4 &s1, const float4 &s2, const float4 &s3 )
+{
+    quad_bcast<0>(acc, G, s0);
+    quad_bcast<4>(acc, G, s1);
+    quad_bcast<8>(acc, G, s2);
+    quad_bcast<12>(acc, G, s3);
+}
+
+// the first `cnt` (1..15) samples of a group, one uniform test per sample
+__device__ __forceinline__ void group_bcast_tail( double (&acc)[4], const TwGroup &G,
+	const float4 &s0, const float4 &s1, const float4 &s2, const float4 &s3, uint32_t cnt )
+{
+#define MIFSK_TAIL(J, X) if ( cnt > (J) ) fma4_bcast<J>(acc, G, X)
+    MIFSK_TAIL(0, s0.x);  MIFSK_TAIL(1, s0.y);  MIFSK_TAIL(2, s0.z);   MIFSK_TAIL(3, s0.w);
+    MIFSK_TAIL(4, s1.x);  MIFSK_TAIL(5, s1.y);  MIFSK_TAIL(6, s1.z);   MIFSK_TAIL(7, s1.w);
+    MIFSK_TAIL(8, s2.x);  MIFSK_TAIL(9, s2.y);  MIFSK_TAIL(10, s2.z);  MIFSK_TAIL(11, s2.w);
+    MIFSK_TAIL(12, s3.x); MIFSK_TAIL(13, s3.y); MIFSK_TAIL(14, s3.z);  MIFSK_TAIL(15, s3.w);
+#undef MIFSK_TAIL
+}
+
+// Window of NQ * 4 samples (NQ <= 12) in LDS at a 16-byte aligned address, its
+// table resident in registers (tg[g] = group g): everything unrolled, all the
+// ds_read_b128 free to issue ahead of the FMAs.
+template <int NQ>
+__device__ __forceinline__ void corr_lds_fixed( const TwGroup (&tg)[3], const float *p, double (&acc)[4] )
+{
+    static_assert(NQ >= 1 && NQ <= 12, "three resident groups");
+    float4 xs[NQ];
+#pragma unroll
+    for ( int q = 0; q < NQ; q++ )
+	xs[q] = *reinterpret_cast<const float4 *>(p + 4 * q);
+    dpp_settle();
+#define MIFSK_QUAD(Q)							\
+    if ( (Q) < NQ ) {							\
+	if ( (Q) % 4 == 0 ) quad_bcast<0>(acc, tg[(Q) / 4], xs[(Q) < NQ ? (Q) : 0]);	\
+	if ( (Q) % 4 == 1 ) quad_bcast<4>(acc, tg[(Q) / 4], xs[(Q) < NQ ? (Q) : 0]);	\
+	if ( (Q) % 4 == 2 ) quad_bcast<8>(acc, tg[(Q) / 4], xs[(Q) < NQ ? (Q) : 0]);	\
+	if ( (Q) % 4 == 3 ) quad_bcast<12>(acc, tg[(Q) / 4], xs[(Q) < NQ ? (Q) : 0]);	\
+    }
+    MIFSK_QUAD(0) MIFSK_QUAD(1) MIFSK_QUAD(2) MIFSK_QUAD(3) MIFSK_QUAD(4) MIFSK_QUAD(5)
+    MIFSK_QUAD(6) MIFSK_QUAD(7) MIFSK_QUAD(8) MIFSK_QUAD(9) MIFSK_QUAD(10) MIFSK_QUAD(11)
+#undef MIFSK_QUAD
+}
+
+// Window of nq * 4 samples in LDS at a 16-byte aligned address, any length: one
+// table group (two 16-byte global loads per lane, L1-resident) and four
+// ds_read_b128 per 16 samples, the next group's loads issued before this
+// group's FMAs.  Reads up to 12 samples past the window (the region has slack).
+__device__ __forceinline__ void corr_lds_stream( const double *__restrict__ tw, const float *p,
+	uint32_t nq, uint32_t lane, double (&acc)[4] )
+{
+    const uint32_t ng = ( nq + 3u ) >> 2;
+    TwGroup G = tw_group_load(tw, 0, lane);
+    float4 s0 = *reinterpret_cast<const float4 *>(p);
+    float4 s1 = *reinterpret_cast<const float4 *>(p + 4);
+    float4 s2 = *reinterpret_cast<const float4 *>(p + 8);
+    float4 s3 = *reinterpret_cast<const float4 *>(p + 12);
+    // every group but the last, with the next one's loads in flight (nothing is
+    // left outstanding at the end: a load nobody waits for makes hipcc drain
+    // vmcnt at the next join, and with it the caller's prefetch)
+    for ( uint32_t g = 0; g + 1u < ng; g++ ) {
+	const TwGroup Gn = tw_group_load(tw, g + 1u, lane);
+	const float *pn = p + 16u * ( g + 1u );
+	const float4 n0 = *reinterpret_cast<const float4 *>(pn);
+	const float4 n1 = *reinterpret_cast<const float4 *>(pn + 4);
+	const float4 n2 = *reinterpret_cast<const float4 *>(pn + 8);
+	const float4 n3 = *reinterpret_cast<const float4 *>(pn + 12);
+	dpp_settle();						// (G may just have been copied)
+	group_bcast(acc, G, s0, s1, s2, s3);
+	G = Gn;
+	s0 = n0; s1 = n1; s2 = n2; s3 = n3;
+    }
+    const uint32_t left = ( nq - 4u * ( ng - 1u ) ) * 4u;	// samples in the last group
+    dpp_settle();
+    if ( left >= 16u )
+	group_bcast(acc, G, s0, s1, s2, s3);
+    else
+	group_bcast_tail(acc, G, s0, s1, s2, s3, left);
+}
+
+// Window of B samples read straight from global memory at x + a (any
+// alignment), any length: 64 bytes per lane per 16 samples, next group in
+// flight.  The caller guarantees a + 16 * ceil(B / 16) <= N (the last group is
+// loaded whole; samples beyond B are not accumulated).
+__device__ __forceinline__ void corr_global_stream( const double *__restrict__ tw,
+	const float *__restrict__ xa, uint32_t B, uint32_t lane, double (&acc)[4] )
+{
+    const uint32_t ng = ( B + 15u ) >> 4;
+    TwGroup G = tw_group_load(tw, 0, lane);
+    float4_u c0 = *reinterpret_cast<const float4_u *>(xa);
+    float4_u c1 = *reinterpret_cast<const float4_u *>(xa + 4);
+    float4_u c2 = *reinterpret_cast<const float4_u *>(xa + 8);
+    float4_u c3 = *reinterpret_cast<const float4_u *>(xa + 12);
+    for ( uint32_t g = 0; g + 1u < ng; g++ ) {		// (see corr_lds_stream: nothing left in flight)
+	const TwGroup Gn = tw_group_load(tw, g + 1u, lane);
+	const float *pn = xa + 16u * ( g + 1u );
+	const float4_u d0 = *reinterpret_cast<const float4_u *>(pn);
+	const float4_u d1 = *reinterpret_cast<const float4_u *>(pn + 4);
+	const float4_u d2 = *reinterpret_cast<const float4_u *>(pn + 8);
+	const float4_u d3 = *reinterpret_cast<const float4_u *>(pn + 12);
+	dpp_settle();						// (G may just have been copied)
+	group_bcast(acc, G, make_float4(c0.x, c0.y, c0.z, c0.w), make_float4(c1.x, c1.y, c1.z, c1.w),
+		    make_float4(c2.x, c2.y, c2.z, c2.w), make_float4(c3.x, c3.y, c3.z, c3.w));
+	G = Gn;
+	c0 = d0; c1 = d1; c2 = d2; c3 = d3;
+    }
+    const uint32_t left = B - 16u * ( ng - 1u );
+    const float4 s0 = make_float4(c0.x, c0.y, c0.z, c0.w), s1 = make_float4(c1.x, c1.y, c1.z, c1.w);
+    const float4 s2 = make_float4(c2.x, c2.y, c2.z, c2.w), s3 = make_float4(c3.x, c3.y, c3.z, c3.w);
+    dpp_settle();
+    if ( left >= 16u )
+	group_bcast(acc, G, s0, s1, s2, s3);
+    else
+	group_bcast_tail(acc, G, s0, s1, s2, s3, left);
+}
+
+// Window held in a SKEWED slab (rows of one bit length, `skew` pad words in
+// between; see store4_skewed), starting `rel` samples after slab row 0: one
+// ds_read_b32 per sample, 16 at a time.
+__device__ __forceinline__ void corr_skewed_stream( const DevCfg &cfg, const double *__restrict__ tw,
+	const float *slab, uint32_t rel, uint32_t lane, double (&acc)[4] )
+{
+    const uint32_t B = cfg.bit_nsamples;
+    uint32_t row, col;
+    divmod_bit(cfg, rel, row, col);
+    const float *p = slab + rel + row * cfg.skew;
+    const uint32_t wrap = B - col;	// first n that falls into the next row
+    const uint32_t skew = cfg.skew;
+    const uint32_t last = B - 1u;
+    const uint32_t ng = ( B + 15u ) >> 4;
+    for ( uint32_t g = 0; g < ng; g++ ) {
+	const TwGroup G = tw_group_load(tw, g, lane);
+	float xs[16];
+#pragma unroll
+	for ( int j = 0; j < 16; j++ ) {
+	    uint32_t n = 16u * g + (uint32_t)j;
+	    n = n < last ? n : last;			// (uniform) never past the window
+	    xs[j] = p[n + ( n >= wrap ? skew : 0u )];
+	}
+	const float4 s0 = make_float4(xs[0], xs[1], xs[2], xs[3]), s1 = make_float4(xs[4], xs[5], xs[6], xs[7]);
+	const float4 s2 = make_float4(xs[8], xs[9], xs[10], xs[11]), s3 = make_float4(xs[12], xs[13], xs[14], xs[15]);
+	const uint32_t left = B - 16u * g;
+	dpp_settle();
+	if ( left >= 16u )
+	    group_bcast(acc, G, s0, s1, s2, s3);
+	else
+	    group_bcast_tail(acc, G, s0, s1, s2, s3, left);
+    }
+}
+
 } // namespace mifsk

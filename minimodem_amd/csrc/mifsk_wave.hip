@@ -122,7 +122,7 @@ __device__ __forceinline__ int wave_detect_window( const float *__restrict__ w, 
 }
 
 // everything the kernel keeps per stream beyond the loop's scalars
-template <int SV>
+template <int SV, int NQ>
 struct Wave {
     static constexpr uint32_t kRoundFloats = 64u * SV * 4u;	// samples one staging round loads
     const DevCfg	&cfg;
@@ -147,6 +147,9 @@ struct Wave {
     // register prefetch of the next LINEAR round
     float4		pbuf[SV];
     uint32_t		pref_lo;
+    // groups 0..2 of the twiddle table (entries 0..47), resident (NQ > 0): what the
+    // linear LATTICE correlator needs for its bit windows of 4 NQ <= 48 samples
+    TwGroup		tgr[3];
     // counters
     uint32_t		n_blocks, n_scans, n_positions, n_hits, n_stages;
     uint32_t		cyc_block, cyc_scan;
@@ -162,6 +165,17 @@ struct Wave {
 #pragma unroll
 	for ( int i = 0; i < SV; i++ )
 	    pbuf[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	load_resident_twiddles();
+    }
+
+    // (again after --auto-carrier has rebuilt the stream's table)
+    __device__ __forceinline__ void load_resident_twiddles()
+    {
+	if constexpr ( NQ > 0 ) {
+#pragma unroll
+	    for ( int gi = 0; gi < ( NQ + 3 ) / 4; gi++ )
+		tgr[gi] = tw_group_load(tw, (uint32_t)gi, lane);
+	}
     }
 
     // nothing prefetched is wanted any more: end the registers' live ranges
@@ -253,15 +267,20 @@ struct Wave {
 	    pref_lo = ok ? next_lo : 0xFFFFFFFFu;
 	}
 	wave_lds_sync();
-	const uint32_t nhalf = ( B + 3u ) >> 2;
+	const uint32_t nq = B >> 2;				// (linear: B % 4 == 0; == NQ when NQ > 0)
 	for ( uint32_t s0 = 0; s0 < nw; s0 += 64u ) {
 	    const uint32_t w = w0 + s0 + lane;
 	    const bool active = s0 + lane < nw;
 	    const uint32_t rel = A + win_rel(active ? w : w0) - lo;	// idle lanes shadow the first window
-	    double mr = 0.0, mi = 0.0, sr = 0.0, si = 0.0;
-	    correlate_linear_asm_h(tw, slab + rel, nhalf, mr, mi, sr, si);
+	    double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
+	    const float *p = slab + rel;
+	    if constexpr ( NQ > 0 )
+		corr_lds_fixed<NQ>(tgr, p, acc);		// the instantiation for this bit length
+	    else
+		corr_lds_stream(tw, p, nq, lane, acc);
 	    if ( active )
-		mags[w] = make_float2(band_mag(mr, mi, cfg.magscalar), band_mag(sr, si, cfg.magscalar));
+		mags[w] = make_float2(band_mag(acc[0], acc[1], cfg.magscalar),
+				      band_mag(acc[2], acc[3], cfg.magscalar));
 	}
 	wave_lds_sync();			// the slab is rewritten by the next round
     }
@@ -277,42 +296,24 @@ struct Wave {
 	const uint32_t w = w0 + lane;
 	const bool active = lane < nw;
 	const uint32_t a = A + win_rel(active ? w : w0);
-	const uint32_t Bpad = ( B + XCH - 1u ) & ~(uint32_t)( XCH - 1 );
-	double mr = 0.0, mi = 0.0, sr = 0.0, si = 0.0;
+	const uint32_t Bpad = ( B + 15u ) & ~15u;		// whole groups of 16 are loaded
+	double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
 	if ( __all(a + Bpad <= N && a + Bpad >= a) ) {
-	    const float *p = x + a;
-	    float4_u c0 = *reinterpret_cast<const float4_u *>(p);
-	    float4_u c1 = *reinterpret_cast<const float4_u *>(p + 4);
-	    for ( uint32_t n0 = 0; n0 < B; n0 += XCH ) {
-		float4_u d0 = c0, d1 = c1;
-		if ( n0 + XCH < B ) {		// uniform: the next chunk, in flight during this one's FMAs
-		    d0 = *reinterpret_cast<const float4_u *>(p + n0 + XCH);
-		    d1 = *reinterpret_cast<const float4_u *>(p + n0 + XCH + 4);
-		}
-		tw8 ta, tb, tc, td;
-		twiddle_fetch_ro(tw + 4 * (size_t)n0, ta, tb, tc, td);
-		twiddle_wait_ro();
-		MIFSK_FMA4(c0.x, ta, 0);  MIFSK_FMA4(c0.y, ta, 1);
-		MIFSK_FMA4(c0.z, tb, 0);  MIFSK_FMA4(c0.w, tb, 1);
-		MIFSK_FMA4(c1.x, tc, 0);  MIFSK_FMA4(c1.y, tc, 1);
-		MIFSK_FMA4(c1.z, td, 0);  MIFSK_FMA4(c1.w, td, 1);
-		c0 = d0;
-		c1 = d1;
-	    }
+	    corr_global_stream(tw, x + a, B, lane, acc);
 	} else {
 	    // a window reaches the end of the stream: per-sample guarded reads
 	    for ( uint32_t n = 0; n < B; n++ ) {
 		const uint32_t idx = a + n;
 		const double xd = (double)( ( idx < N && idx >= a ) ? x[idx] : 0.0f );
 		const double *t = tw + 4 * (size_t)n;
-		mr = fma(xd, t[0], mr);
-		mi = fma(xd, t[1], mi);
-		sr = fma(xd, t[2], sr);
-		si = fma(xd, t[3], si);
+		acc[0] = fma(xd, t[0], acc[0]);
+		acc[1] = fma(xd, t[1], acc[1]);
+		acc[2] = fma(xd, t[2], acc[2]);
+		acc[3] = fma(xd, t[3], acc[3]);
 	    }
 	}
 	if ( active )
-	    mags[w] = make_float2(band_mag(mr, mi, cfg.magscalar), band_mag(sr, si, cfg.magscalar));
+	    mags[w] = make_float2(band_mag(acc[0], acc[1], cfg.magscalar), band_mag(acc[2], acc[3], cfg.magscalar));
     }
 
     // Evaluate F lattice frames anchored at A (first-try position of frame 0).
@@ -421,31 +422,11 @@ struct Wave {
 	    const uint32_t a = base + zz.at(c0 + q) + cfg.bit_offset[k & 63u];
 	    double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
 	    if ( use_slab ) {
-		correlate_window(cfg, tw, slab, a - slab_lo, active, acc);
-	    } else if ( !ring && __all(a + ( ( B + 7u ) & ~7u ) <= N && a + B + 8u >= a) ) {
+		corr_skewed_stream(cfg, tw, slab, a - slab_lo, lane, acc);
+	    } else if ( !ring && __all(a + ( ( B + 15u ) & ~15u ) <= N && a + B + 16u >= a) ) {
 		// long windows (or no slab at this occupancy): stream from global
-		// memory, 32 bytes per lane per step, next chunk in flight
-		const float *p = x + a;
-		float4_u c0v = *reinterpret_cast<const float4_u *>(p);
-		float4_u c1v = *reinterpret_cast<const float4_u *>(p + 4);
-		double mr = 0.0, mi = 0.0, sr = 0.0, si = 0.0;
-		for ( uint32_t n0 = 0; n0 < B; n0 += XCH ) {
-		    float4_u d0 = c0v, d1 = c1v;
-		    if ( n0 + XCH < B ) {
-			d0 = *reinterpret_cast<const float4_u *>(p + n0 + XCH);
-			d1 = *reinterpret_cast<const float4_u *>(p + n0 + XCH + 4);
-		    }
-		    tw8 ta, tb, tc, td;
-		    twiddle_fetch_ro(tw + 4 * (size_t)n0, ta, tb, tc, td);
-		    twiddle_wait_ro();
-		    MIFSK_FMA4(c0v.x, ta, 0);  MIFSK_FMA4(c0v.y, ta, 1);
-		    MIFSK_FMA4(c0v.z, tb, 0);  MIFSK_FMA4(c0v.w, tb, 1);
-		    MIFSK_FMA4(c1v.x, tc, 0);  MIFSK_FMA4(c1v.y, tc, 1);
-		    MIFSK_FMA4(c1v.z, td, 0);  MIFSK_FMA4(c1v.w, td, 1);
-		    c0v = d0;
-		    c1v = d1;
-		}
-		acc[0] = mr; acc[1] = mi; acc[2] = sr; acc[3] = si;
+		// memory, 64 bytes per lane per 16 samples, next group in flight
+		corr_global_stream(tw, x + a, B, lane, acc);
 	    } else {
 		for ( uint32_t n = 0; n < B; n++ ) {
 		    const uint32_t idx = a + n;
@@ -568,8 +549,10 @@ __device__ __forceinline__ uint64_t lane_gather64( uint64_t v, uint32_t src )
 
 extern __shared__ __attribute__((aligned(16))) unsigned char mifsk_wave_smem[];
 
-template <int SV>
-__global__ __launch_bounds__(64, 4)
+// (the wide-staging instantiation runs where a wave has >= 10 KiB of LDS to
+// itself, i.e. at most 2-3 waves per SIMD: it may use 256 VGPRs)
+template <int SV, int NQ>
+__global__ __launch_bounds__(64, SV >= 10 ? 2 : 4)
 void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restrict__ tw_default,
 	mifsk_demod_io io, WaveGeom g, WaveAuto au )
 {
@@ -593,9 +576,9 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
     uint32_t safe_limit = rows_after == 0 ? N
 			: rows_after > 0xFFFF0000ull ? 0xFFFF0000u : (uint32_t)rows_after;
     bool lattice_ok = g.lat_mode != LAT_NONE;
-    if ( g.lat_mode == LAT_LINEAR && safe_limit < Wave<SV>::kRoundFloats ) {
+    if ( g.lat_mode == LAT_LINEAR && safe_limit < Wave<SV, NQ>::kRoundFloats ) {
 	lattice_ok = false;
-	safe_limit = Wave<SV>::kRoundFloats;
+	safe_limit = Wave<SV, NQ>::kRoundFloats;
     }
     float *ring = g.ring_exact ? au.d_ring + (size_t)s * g.ring_stride : nullptr;
     if ( ring )
@@ -615,7 +598,7 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
     o.frames = io.d_frames ? io.d_frames + (size_t)s * io.frames_cap : nullptr;
     o.eps = io.d_episodes ? io.d_episodes + (size_t)s * io.episodes_cap : nullptr;
 
-    Wave<SV> ctx(cfg, g, tw, x, N, mags, slab, ring, safe_limit);
+    Wave<SV, NQ> ctx(cfg, g, tw, x, N, mags, slab, ring, safe_limit);
 
     // reference loop state (minimodem.c:1079-1088,1132-1133), uniform in the wave
     bool carrier = false;
@@ -886,6 +869,7 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 	    // in the tail paths): complete the stores, then drop stale lines
 	    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
 	    __builtin_amdgcn_s_dcache_inv();
+	    ctx.load_resident_twiddles();
 	    ctx.lat_n = 0;				// scored with the old tones
 	    ctx.slab_lo = ctx.slab_hi = 0;
 	}
@@ -1229,17 +1213,29 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
     au.d_tw_scratch = ha.d_tw_scratch;
     au.d_ring = ha.d_ring;
 
+    // the instantiation: staging width x resident-table correlator for the bit
+    // lengths that have one (linear LATTICE only)
+    const uint32_t nq = ( g.lat_mode == LAT_LINEAR && cfg.bit_nsamples % 4u == 0u ) ? cfg.bit_nsamples / 4u : 0u;
     hipStream_t st = (hipStream_t)stream;
-    const void *fn = plan.sv == 10 ? reinterpret_cast<const void *>(&demod_wave_kernel<10>)
-				   : reinterpret_cast<const void *>(&demod_wave_kernel<4>);
-    if ( hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes) != hipSuccess )
-	return -5;
-    if ( plan.sv == 10 )
-	hipLaunchKernelGGL(demod_wave_kernel<10>, dim3((unsigned)io.nstreams), dim3(64), plan.lds_bytes, st,
-			   d_cfg, d_tw, io, g, au);
-    else
-	hipLaunchKernelGGL(demod_wave_kernel<4>, dim3((unsigned)io.nstreams), dim3(64), plan.lds_bytes, st,
-			   d_cfg, d_tw, io, g, au);
+#define MIFSK_WAVE_LAUNCH(SV_, NQ_)										\
+    do {													\
+	const void *fn = reinterpret_cast<const void *>(&demod_wave_kernel<SV_, NQ_>);				\
+	if ( hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes)		\
+		!= hipSuccess )											\
+	    return -5;												\
+	hipLaunchKernelGGL((demod_wave_kernel<SV_, NQ_>), dim3((unsigned)io.nstreams), dim3(64),		\
+			   plan.lds_bytes, st, d_cfg, d_tw, io, g, au);						\
+    } while (0)
+    if ( plan.sv == 10 ) {
+	if ( nq == 10u )     MIFSK_WAVE_LAUNCH(10, 10);		// 1200 baud at 48 kHz
+	else if ( nq == 5u ) MIFSK_WAVE_LAUNCH(10, 5);		// 2400 baud; 1200 baud at 24 kHz
+	else                 MIFSK_WAVE_LAUNCH(10, 0);
+    } else {
+	if ( nq == 10u )     MIFSK_WAVE_LAUNCH(4, 10);
+	else if ( nq == 1u ) MIFSK_WAVE_LAUNCH(4, 1);		// 12000 baud
+	else                 MIFSK_WAVE_LAUNCH(4, 0);
+    }
+#undef MIFSK_WAVE_LAUNCH
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
