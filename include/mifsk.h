@@ -253,6 +253,10 @@ typedef struct mifsk_demod_io {
  * worker waves; the round-1 kernel) instead of one wavefront per stream.
  * Flat addressing only; --auto-carrier looks for the tone once per stream. */
 #define MIFSK_IO_ENGINE_WORKGROUP 2u
+/* ... or with one wavefront per stream whatever the batch looks like.  With
+ * neither flag the library chooses (the workgroup engine for batches of fewer
+ * streams than two wavefronts per SIMD in the modes it pipelines). */
+#define MIFSK_IO_ENGINE_WAVE	4u
 
 /* per-stream work counters (diagnostics; cycle counts are s_memtime ticks) */
 #define MIFSK_NCOUNTERS		24

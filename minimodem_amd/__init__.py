@@ -125,7 +125,7 @@ def max_frames(cfg, nsamples):
 
 def demod_batch(ctx, cfg, samples, nsamples=None, want=("bytes", "episodes"),
                 frames_cap=None, episodes_cap=8, stream=None, out=None, ring_exact=False,
-                engine=None):
+                engine=None, force_engine=False):
     """Run the receive loop over a batch of streams resident in HBM.
 
     samples : torch.float32 CUDA tensor [nstreams, stride] (stride % 4 == 0)
@@ -134,8 +134,9 @@ def demod_batch(ctx, cfg, samples, nsamples=None, want=("bytes", "episodes"),
     `out` may be a dict returned by a previous call with the same shapes, to
     reuse its buffers (nothing is allocated inside the timed region then).
     ring_exact: MIFSK_IO_RING_EXACT (the reference's stale-cell buffer semantics).
-    engine: None (one wavefront per stream) or "workgroup" (one 256-thread
-    workgroup per stream, MIFSK_IO_ENGINE_WORKGROUP).
+    engine: None (the library chooses), "wave" (one wavefront per stream,
+    MIFSK_IO_ENGINE_WAVE) or "workgroup" (one 256-thread workgroup per stream,
+    MIFSK_IO_ENGINE_WORKGROUP); force_engine=True makes None mean "wave".
     """
     torch = _torch()
     lib = _lib.load()
@@ -192,8 +193,11 @@ def demod_batch(ctx, cfg, samples, nsamples=None, want=("bytes", "episodes"),
     io.d_status = ptr("status")
     io.d_counters = ptr("counters")
     io.d_carrier_band = ptr("carrier_band")
+    if engine is None and force_engine:
+        engine = "wave"
     io.flags = (_lib.IO_RING_EXACT if ring_exact else 0) | \
-        (_lib.IO_ENGINE_WORKGROUP if engine == "workgroup" else 0)
+        (_lib.IO_ENGINE_WORKGROUP if engine == "workgroup" else 0) | \
+        (_lib.IO_ENGINE_WAVE if engine == "wave" else 0)
     rc = lib.mifsk_demod_batch(ctx.handle, C.byref(cfg), C.byref(io), _stream_ptr(torch, stream))
     if rc != 0:
         raise RuntimeError("mifsk_demod_batch failed: %d" % rc)

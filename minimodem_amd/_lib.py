@@ -138,6 +138,7 @@ class DemodIO(C.Structure):
 
 IO_RING_EXACT = 1
 IO_ENGINE_WORKGROUP = 2
+IO_ENGINE_WAVE = 4
 
 
 class FskPlan(C.Structure):

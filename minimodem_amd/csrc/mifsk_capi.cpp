@@ -125,6 +125,7 @@ struct CfgEntry {
 
 struct mifsk_ctx {
     int			device;
+    int			ncu;		// compute units (occupancy planning)
     char		name[256];
     std::mutex		lock;
     std::vector<TwEntry>	tables;
@@ -132,11 +133,6 @@ struct mifsk_ctx {
     // spectrum table for fsk_detect_carrier
     unsigned		cs_fftsize;
     double		*d_cs;
-    // --auto-carrier scratch (grow-only): per-stream band, start cursor, table pointer
-    size_t		auto_cap;
-    int32_t		*d_auto_band;
-    uint32_t		*d_auto_start;
-    const double	**d_auto_tw;
 };
 
 #define HIP_OK(call)	do { hipError_t e_ = (call); if ( e_ != hipSuccess ) { \
@@ -175,13 +171,10 @@ extern "C" int mifsk_ctx_create( mifsk_ctx **out, int device )
     if ( !ctx )
 	return -ENOMEM;
     ctx->device = device;
+    ctx->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     std::snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
     ctx->cs_fftsize = 0;
     ctx->d_cs = nullptr;
-    ctx->auto_cap = 0;
-    ctx->d_auto_band = nullptr;
-    ctx->d_auto_start = nullptr;
-    ctx->d_auto_tw = nullptr;
     *out = ctx;
     return 0;
 }
@@ -196,9 +189,6 @@ extern "C" void mifsk_ctx_destroy( mifsk_ctx *ctx )
 	(void)hipFree(e.dev);
     if ( ctx->d_cs )
 	(void)hipFree(ctx->d_cs);
-    if ( ctx->d_auto_band ) (void)hipFree(ctx->d_auto_band);
-    if ( ctx->d_auto_start ) (void)hipFree(ctx->d_auto_start);
-    if ( ctx->d_auto_tw ) (void)hipFree(ctx->d_auto_tw);
     delete ctx;
 }
 
@@ -250,6 +240,8 @@ static int get_devcfg( mifsk_ctx *ctx, const DevCfg &d, const DevCfg **d_out )
 	    return 0;
 	}
     if ( ctx->configs.size() >= 64 ) {		// bounded cache (legacy API makes one per window shape)
+	// kernels launched on any stream may still be reading these copies
+	(void)hipDeviceSynchronize();
 	for ( CfgEntry &e : ctx->configs )
 	    (void)hipFree(e.dev);
 	ctx->configs.clear();
@@ -265,7 +257,10 @@ static int get_devcfg( mifsk_ctx *ctx, const DevCfg &d, const DevCfg **d_out )
 // cos / -sin of 2 pi k / N for k < N (the spectrum table of fsk_detect_carrier)
 static int get_cs( mifsk_ctx *ctx, unsigned N, const double **d_out )
 {
+    std::lock_guard<std::mutex> g(ctx->lock);
     if ( ctx->cs_fftsize != N ) {
+	if ( ctx->d_cs )
+	    (void)hipDeviceSynchronize();	// (a kernel in flight may be reading the old table)
 	std::vector<double> h(2 * (size_t)N);
 	for ( unsigned k = 0; k < N; k++ ) {
 	    const double ang = 2.0 * M_PI * (double)k / (double)N;
@@ -318,76 +313,6 @@ extern "C" int mifsk_find_frame_batch( mifsk_ctx *ctx, const mifsk_rx_config *cf
 					  nproblems, stream);
 }
 
-// --auto-carrier (minimodem.c:1179-1220): scan every stream for its mark tone on
-// the device, fetch the bands, give each stream the twiddle table of its own
-// (mark, space) pair, then run the receive loop from where the scan stopped.
-// One host round trip in the middle, so this path synchronises `stream` once.
-static int demod_batch_auto( mifsk_ctx *ctx, const mifsk_rx_config *cfg, const DevCfg &d,
-	const DevCfg *d_cfg, const double *d_tw_default, const mifsk_demod_io *io, void *stream )
-{
-    const size_t ns = (size_t)io->nstreams;
-    if ( ctx->auto_cap < ns ) {
-	if ( ctx->d_auto_band ) (void)hipFree(ctx->d_auto_band);
-	if ( ctx->d_auto_start ) (void)hipFree(ctx->d_auto_start);
-	if ( ctx->d_auto_tw ) (void)hipFree(ctx->d_auto_tw);
-	ctx->d_auto_band = nullptr; ctx->d_auto_start = nullptr; ctx->d_auto_tw = nullptr;
-	ctx->auto_cap = 0;
-	if ( hipMalloc(&ctx->d_auto_band, ns * sizeof(int32_t)) != hipSuccess
-		|| hipMalloc(&ctx->d_auto_start, ns * sizeof(uint32_t)) != hipSuccess
-		|| hipMalloc(&ctx->d_auto_tw, ns * sizeof(double *)) != hipSuccess )
-	    return -ENOMEM;
-	ctx->auto_cap = ns;
-    }
-    const double *d_cs = nullptr;
-    int rc = get_cs(ctx, (unsigned)cfg->fftsize, &d_cs);
-    if ( rc )
-	return rc;
-    // default negative shift, in the reference's float arithmetic (minimodem.c:1203-1206)
-    int b_shift = - (float)( cfg->autodetect_shift + cfg->band_width / 2.0f ) / cfg->band_width;
-    if ( cfg->inverted_freqs )
-	b_shift *= -1;
-    if ( b_shift == 0 )
-	return -EINVAL;			// assert in fsk_set_tones_by_bandshift (fsk.c:587)
-    mifsk::CarrierScanArgs a;
-    a.d_samples = io->d_samples;
-    a.stream_stride = io->stream_stride;
-    a.d_nsamples = io->d_nsamples;
-    a.nsamples = io->nsamples;
-    a.nstreams = io->nstreams;
-    a.d_cs = d_cs;
-    a.fftsize = (uint32_t)cfg->fftsize;
-    a.nbands = cfg->nbands;
-    a.nsamples_per_scan = cfg->nsamples_per_bit > (float)cfg->fftsize ? (float)cfg->fftsize
-								       : cfg->nsamples_per_bit;
-    a.threshold = cfg->auto_carrier_threshold;
-    a.samplebuf_size = cfg->samplebuf_size;
-    a.b_shift = b_shift;
-    a.d_band = ctx->d_auto_band;
-    a.d_start = ctx->d_auto_start;
-    rc = mifsk::launch_carrier_scan(a, stream);
-    if ( rc )
-	return rc;
-    std::vector<int32_t> band(ns);
-    HIP_OK(hipMemcpyAsync(band.data(), ctx->d_auto_band, ns * sizeof(int32_t),
-			  hipMemcpyDeviceToHost, (hipStream_t)stream));
-    HIP_OK(hipStreamSynchronize((hipStream_t)stream));
-    std::vector<const double *> tw(ns, d_tw_default);
-    for ( size_t s = 0; s < ns; s++ ) {
-	if ( band[s] < 0 )
-	    continue;
-	rc = get_twiddles(ctx, TwKey{(unsigned)cfg->fftsize, (unsigned)band[s],
-				     (unsigned)( band[s] + b_shift ), cfg->bit_nsamples}, &tw[s]);
-	if ( rc )
-	    return rc;
-    }
-    HIP_OK(hipMemcpy(ctx->d_auto_tw, tw.data(), ns * sizeof(double *), hipMemcpyHostToDevice));
-    if ( io->d_carrier_band )
-	HIP_OK(hipMemcpyAsync(io->d_carrier_band, ctx->d_auto_band, ns * sizeof(int32_t),
-			      hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    return mifsk::launch_demod_batch(d, d_cfg, d_tw_default, *io, stream, ctx->d_auto_tw,
-				     ctx->d_auto_start);
-}
-
 // One wavefront per stream (mifsk_wave.hip): --auto-carrier and RING addressing
 // need per-call device scratch; it is allocated and freed in stream order, so
 // concurrent calls on different streams never share it.
@@ -398,6 +323,7 @@ static int demod_batch_wave( mifsk_ctx *ctx, const mifsk_rx_config *cfg, const D
     const size_t ns = (size_t)io->nstreams;
     mifsk::WaveHostArgs ha;
     std::memset(&ha, 0, sizeof(ha));
+    ha.ncu = ctx->ncu;
     ha.samplebuf_size = cfg->samplebuf_size;
     ha.fftsize = (uint32_t)cfg->fftsize;
     ha.nbands = cfg->nbands;
@@ -456,9 +382,9 @@ extern "C" int mifsk_demod_batch( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
 	return -EINVAL;		// rows must be 16-byte aligned (coalesced float4 staging)
     if ( ( io->d_bytes || io->d_bits || io->d_frames ) && io->frames_cap == 0 )
 	return -EINVAL;
-    if ( io->flags & ~( MIFSK_IO_RING_EXACT | MIFSK_IO_ENGINE_WORKGROUP ) )
+    if ( io->flags & ~( MIFSK_IO_RING_EXACT | MIFSK_IO_ENGINE_WORKGROUP | MIFSK_IO_ENGINE_WAVE ) )
 	return -EINVAL;
-    if ( ( io->flags & MIFSK_IO_RING_EXACT ) && ( io->flags & MIFSK_IO_ENGINE_WORKGROUP ) )
+    if ( ( io->flags & MIFSK_IO_ENGINE_WORKGROUP ) && ( io->flags & MIFSK_IO_ENGINE_WAVE ) )
 	return -EINVAL;
     HIP_OK(hipSetDevice(ctx->device));
     const double *d_tw = nullptr;
@@ -474,13 +400,21 @@ extern "C" int mifsk_demod_batch( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
 	return rc;
     if ( io->nstreams == 0 )
 	return 0;
-    bool workgroup = ( io->flags & MIFSK_IO_ENGINE_WORKGROUP ) != 0;
+    // Engine.  One wavefront per stream is the general engine (every option,
+    // any stream count).  A batch with fewer streams than two waves per SIMD
+    // leaves a lone wave nothing to hide its latencies behind; where the
+    // workgroup engine has its pipelined linear LATTICE (bit length and frame
+    // step in multiples of 4 samples: Bell-202, 2400 baud, ...) it spreads each
+    // stream over four waves instead.  Identical results either way.
+    const bool plain = !( io->flags & MIFSK_IO_RING_EXACT ) && !( cfg->auto_carrier_threshold > 0.0f );
+    bool workgroup = plain && !( io->flags & MIFSK_IO_ENGINE_WAVE )
+		  && ( ( io->flags & MIFSK_IO_ENGINE_WORKGROUP )
+		       || ( d.lat_linear && (long)io->nstreams < 8L * ctx->ncu ) );
     if ( const char *e = std::getenv("MIFSK_ENGINE") )	// diagnostic override: "workgroup" / "wave"
-	workgroup = e[0] == 'w' && e[1] == 'o' && !( io->flags & MIFSK_IO_RING_EXACT );
+	if ( !( io->flags & ( MIFSK_IO_ENGINE_WORKGROUP | MIFSK_IO_ENGINE_WAVE ) ) )
+	    workgroup = plain && e[0] == 'w' && e[1] == 'o';
     if ( !workgroup )
 	return demod_batch_wave(ctx, cfg, d, d_cfg, d_tw, io, stream);
-    if ( cfg->auto_carrier_threshold > 0.0f )
-	return demod_batch_auto(ctx, cfg, d, d_cfg, d_tw, io, stream);
     return mifsk::launch_demod_batch(d, d_cfg, d_tw, *io, stream);
 }
 

@@ -105,6 +105,7 @@ struct WaveAuto {
 
 // what the host glue hands the launcher besides cfg / io
 struct WaveHostArgs {
+    int		ncu;		// compute units of the device
     uint32_t	samplebuf_size;
     bool	ring_exact;
     uint32_t	ring_stride;
@@ -121,25 +122,6 @@ struct WaveHostArgs {
 
 int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_tw,
 	const mifsk_demod_io &io, const WaveHostArgs &ha, void *stream );
-
-// --auto-carrier scan (mifsk_carrier.hip): per stream the band the mark tone is
-// first detected in (-1: never) and the cursor the receive loop starts at
-struct CarrierScanArgs {
-    const float		*d_samples;
-    size_t		stream_stride;
-    const uint32_t	*d_nsamples;
-    uint32_t		nsamples;
-    int			nstreams;
-    const double	*d_cs;		// [fftsize][2]: cos, -sin of 2 pi k / fftsize
-    uint32_t		fftsize, nbands;
-    float		nsamples_per_scan;	// min(nsamples_per_bit, fftsize), minimodem.c:1182-1184
-    float		threshold;
-    uint32_t		samplebuf_size;
-    int			b_shift;	// space band = mark band + b_shift, minimodem.c:1203-1206
-    int32_t		*d_band;	// out [nstreams]
-    uint32_t		*d_start;	// out [nstreams]
-};
-int launch_carrier_scan( const CarrierScanArgs &a, void *stream );
 
 int launch_detect_carrier( const float *d_samples, unsigned nsamples,
 	const double *d_cs /* [fftsize][2] */, unsigned fftsize, unsigned nbands,

@@ -835,6 +835,101 @@ __device__ __forceinline__ void corr_lds_fixed( const TwGroup (&tg)[3], const fl
 #undef MIFSK_QUAD
 }
 
+// The same in two halves (quads [0, H) then [H, NQ)), for kernels whose register
+// budget cannot hold a whole window's samples at once (128 VGPRs at four waves
+// per SIMD, where the other waves cover the second batch's LDS latency).
+template <int NQ>
+__device__ __forceinline__ void corr_lds_fixed_halves( const TwGroup (&tg)[3], const float *p, double (&acc)[4] )
+{
+    static_assert(NQ >= 2 && NQ <= 12, "three resident groups");
+    constexpr int H = ( NQ + 1 ) / 2;
+    float4 xs[H];
+#pragma unroll
+    for ( int q = 0; q < H; q++ )
+	xs[q] = *reinterpret_cast<const float4 *>(p + 4 * q);
+    dpp_settle();
+#define MIFSK_QUADH(Q, X)								\
+    {											\
+	if ( (Q) % 4 == 0 ) quad_bcast<0>(acc, tg[(Q) / 4 < 3 ? (Q) / 4 : 0], X);		\
+	if ( (Q) % 4 == 1 ) quad_bcast<4>(acc, tg[(Q) / 4 < 3 ? (Q) / 4 : 0], X);		\
+	if ( (Q) % 4 == 2 ) quad_bcast<8>(acc, tg[(Q) / 4 < 3 ? (Q) / 4 : 0], X);		\
+	if ( (Q) % 4 == 3 ) quad_bcast<12>(acc, tg[(Q) / 4 < 3 ? (Q) / 4 : 0], X);		\
+    }
+    if ( 0 < H ) MIFSK_QUADH(0, xs[0])
+    if ( 1 < H ) MIFSK_QUADH(1, xs[1 < H ? 1 : 0])
+    if ( 2 < H ) MIFSK_QUADH(2, xs[2 < H ? 2 : 0])
+    if ( 3 < H ) MIFSK_QUADH(3, xs[3 < H ? 3 : 0])
+    if ( 4 < H ) MIFSK_QUADH(4, xs[4 < H ? 4 : 0])
+    if ( 5 < H ) MIFSK_QUADH(5, xs[5 < H ? 5 : 0])
+    __builtin_amdgcn_sched_barrier(0);
+    float4 ys[H];
+#pragma unroll
+    for ( int q = 0; q < H; q++ )
+	ys[q] = *reinterpret_cast<const float4 *>(p + 4 * ( H + q < NQ ? H + q : NQ - 1 ));
+    if ( H + 0 < NQ ) MIFSK_QUADH(H + 0, ys[0])
+    if ( H + 1 < NQ ) MIFSK_QUADH(H + 1, ys[1 < H ? 1 : 0])
+    if ( H + 2 < NQ ) MIFSK_QUADH(H + 2, ys[2 < H ? 2 : 0])
+    if ( H + 3 < NQ ) MIFSK_QUADH(H + 3, ys[3 < H ? 3 : 0])
+    if ( H + 4 < NQ ) MIFSK_QUADH(H + 4, ys[4 < H ? 4 : 0])
+    if ( H + 5 < NQ ) MIFSK_QUADH(H + 5, ys[5 < H ? 5 : 0])
+#undef MIFSK_QUADH
+}
+
+// Two windows per lane, interleaved: a dependent f64 FMA can issue only every
+// ~28 cycles, so the four accumulators of one window keep a lone wave at 7
+// cycles per FMA (tools/ubench/dpp_fmac.hip); eight independent chains reach the
+// pipe's 4.  Both windows consume entry n at the same step, so one broadcast
+// register serves both.  Per window the operations and their order are those of
+// corr_lds_fixed.
+template <int J>
+__device__ __forceinline__ void fma4_bcast2( double (&a)[4], double (&b)[4], const TwGroup &G, float xa, float xb )
+{
+    const double da = (double)xa, db = (double)xb;
+    fmac_bcast<J>(a[0], G.w[0], da);
+    fmac_bcast<J>(b[0], G.w[0], db);
+    fmac_bcast<J>(a[1], G.w[1], da);
+    fmac_bcast<J>(b[1], G.w[1], db);
+    fmac_bcast<J>(a[2], G.w[2], da);
+    fmac_bcast<J>(b[2], G.w[2], db);
+    fmac_bcast<J>(a[3], G.w[3], da);
+    fmac_bcast<J>(b[3], G.w[3], db);
+}
+
+template <int J0>
+__device__ __forceinline__ void quad_bcast2( double (&a)[4], double (&b)[4], const TwGroup &G,
+	const float4 &sa, const float4 &sb )
+{
+    fma4_bcast2<J0>(a, b, G, sa.x, sb.x);
+    fma4_bcast2<J0 + 1>(a, b, G, sa.y, sb.y);
+    fma4_bcast2<J0 + 2>(a, b, G, sa.z, sb.z);
+    fma4_bcast2<J0 + 3>(a, b, G, sa.w, sb.w);
+}
+
+template <int NQ>
+__device__ __forceinline__ void corr_lds_fixed2( const TwGroup (&tg)[3], const float *pa, const float *pb,
+	double (&a)[4], double (&b)[4] )
+{
+    static_assert(NQ >= 1 && NQ <= 12, "three resident groups");
+    float4 xa[NQ], xb[NQ];
+#pragma unroll
+    for ( int q = 0; q < NQ; q++ ) {
+	xa[q] = *reinterpret_cast<const float4 *>(pa + 4 * q);
+	xb[q] = *reinterpret_cast<const float4 *>(pb + 4 * q);
+    }
+    dpp_settle();
+#define MIFSK_QUAD2(Q)									\
+    if ( (Q) < NQ ) {									\
+	constexpr int qq = (Q) < NQ ? (Q) : 0;						\
+	if ( (Q) % 4 == 0 ) quad_bcast2<0>(a, b, tg[(Q) / 4], xa[qq], xb[qq]);		\
+	if ( (Q) % 4 == 1 ) quad_bcast2<4>(a, b, tg[(Q) / 4], xa[qq], xb[qq]);		\
+	if ( (Q) % 4 == 2 ) quad_bcast2<8>(a, b, tg[(Q) / 4], xa[qq], xb[qq]);		\
+	if ( (Q) % 4 == 3 ) quad_bcast2<12>(a, b, tg[(Q) / 4], xa[qq], xb[qq]);		\
+    }
+    MIFSK_QUAD2(0) MIFSK_QUAD2(1) MIFSK_QUAD2(2) MIFSK_QUAD2(3) MIFSK_QUAD2(4) MIFSK_QUAD2(5)
+    MIFSK_QUAD2(6) MIFSK_QUAD2(7) MIFSK_QUAD2(8) MIFSK_QUAD2(9) MIFSK_QUAD2(10) MIFSK_QUAD2(11)
+#undef MIFSK_QUAD2
+}
+
 // Window of nq * 4 samples in LDS at a 16-byte aligned address, any length: one
 // table group (two 16-byte global loads per lane, L1-resident) and four
 // ds_read_b128 per 16 samples, the next group's loads issued before this

@@ -254,7 +254,7 @@ __device__ __forceinline__ void par_correlate( const DevCfg &cfg, const double *
 	const uint32_t a = lds->c_pos[q] + cfg.bit_offset[k];
 	double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
 	if ( USE_SLAB ) {
-	    correlate_window(cfg, tw, lds->slab, a - row_org, active, acc);
+	    corr_skewed_stream(cfg, tw, lds->slab, a - row_org, threadIdx.x & 63u, acc);
 	} else {
 	    for ( uint32_t n = 0; n < B; n++ ) {
 		const uint32_t idx = a + n;
@@ -964,11 +964,12 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 }
 
 
+template <int NQ>
 __device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const double *__restrict__ tw,
 	StreamLds *lds, const StreamLds::Cmd *cmd, const float *__restrict__ x, uint32_t N,
 	uint32_t region_floats, uint32_t lat_frames, uint32_t wkr, uint32_t done, uint32_t win_base,
 	uint32_t rel_lane, uint32_t safe_limit,
-	float4 (&pbuf)[STAGE_VEC], uint32_t &pref_org4, uint32_t (&wcyc)[3] )
+	float4 (&pbuf)[STAGE_VEC], uint32_t &pref_org4, uint32_t (&wcyc)[3], const TwGroup (&tgr)[3] )
 {
     uint32_t lane = threadIdx.x & 63u;
     asm volatile("" : "+v"(lane));	// per-round values derived from it are recomputed, not spilled
@@ -1073,7 +1074,17 @@ __device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const 
 	const uint32_t t_mid = MIFSK_CLOCK();
 
 	double mr = 0.0, mi = 0.0, sr = 0.0, si = 0.0;
-	correlate_linear_asm(tw, region + ( a - lo ), ( B + XCH - 1 ) / XCH, mr, mi, sr, si);
+	if constexpr ( NQ > 0 ) {
+	    // an instantiation for this bit length (B == 4 NQ): the table is
+	    // resident in vector registers (three groups of 16 entries) and
+	    // broadcast with DPP -- no scalar loads, no SGPR block for the compiler
+	    // to spill around
+	    double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
+	    corr_lds_fixed_halves<NQ>(tgr, region + ( a - lo ), acc);
+	    mr = acc[0]; mi = acc[1]; sr = acc[2]; si = acc[3];
+	} else {
+	    correlate_linear_asm(tw, region + ( a - lo ), ( B + XCH - 1 ) / XCH, mr, mi, sr, si);
+	}
 	if ( active )
 	    lds->mags[buf][win_base + w] = make_float2(band_mag(mr, mi, cfg.magscalar),
 							   band_mag(sr, si, cfg.magscalar));
@@ -1169,7 +1180,7 @@ __device__ __forceinline__ void worker_lattice_direct( const DevCfg &cfg, const 
 // The worker waves' whole life.  A real (non-inlined) function on purpose: it
 // gets its own register allocation, so the 64 SGPRs of twiddles that the
 // correlator wants in flight do not compete with the master's scalar state.
-template <bool USE_SLAB>
+template <bool USE_SLAB, int NQ>
 __device__ __forceinline__ void worker_main( const DevCfg *__restrict__ cfgp,
 	const double *__restrict__ tw, StreamLds *lds, const float *__restrict__ x, uint32_t N,
 	uint32_t slab_cap, uint32_t lat_frames, uint32_t region_floats, uint32_t region_cap,
@@ -1192,6 +1203,14 @@ __device__ __forceinline__ void worker_main( const DevCfg *__restrict__ cfgp,
 #pragma unroll
     for ( int i = 0; i < STAGE_VEC; i++ )
 	pbuf[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    // groups 0..2 of the twiddle table, one entry per lane of each 16-lane row
+    // (the table is padded to at least 48 entries)
+    TwGroup tgr[3];
+    if constexpr ( NQ > 0 ) {
+#pragma unroll
+	for ( int gi = 0; gi < ( NQ + 3 ) / 4; gi++ )
+	    tgr[gi] = tw_group_load(tw, (uint32_t)gi, threadIdx.x & 63u);
+    }
     uint32_t pref_org4 = 0xFFFFFFFFu;
     uint32_t wcyc[3] = { 0, 0, 0 };
     for ( uint32_t seq = 0; ; seq++ ) {
@@ -1220,10 +1239,10 @@ __device__ __forceinline__ void worker_main( const DevCfg *__restrict__ cfgp,
 		    // the issue slots are better spent by the other workgroups' waves
 		    if ( *(volatile uint32_t *)&lds->abort == seq + 1u )
 			break;
-		    worker_lattice_linear(cfg, tw, lds, cmd, x, N, region_floats, lat_frames,
-					  wkr, done, win_base, rel_lane, safe_limit, pbuf, pref_org4, wcyc);
+		    worker_lattice_linear<NQ>(cfg, tw, lds, cmd, x, N, region_floats, lat_frames,
+					  wkr, done, win_base, rel_lane, safe_limit, pbuf, pref_org4, wcyc, tgr);
 		}
-	    } else {
+	    } else if constexpr ( NQ == 0 ) {	// (an instantiation for one bit length is linear by construction)
 		const uint32_t total = cmd->frames;
 		uint32_t win_base = 0;
 		for ( uint32_t done = 0; done < total; done += lat_frames, win_base += wins_per_round ) {
@@ -1246,7 +1265,7 @@ __device__ __forceinline__ void worker_main( const DevCfg *__restrict__ cfgp,
 #endif
 }
 
-template <bool USE_SLAB>
+template <bool USE_SLAB, int NQ>
 __global__ __launch_bounds__(BLOCK, 4)
 void demod_kernel( const DevCfg *__restrict__ cfgp, const double *__restrict__ tw,
 	mifsk_demod_io io, uint32_t slab_cap, uint32_t lat_frames, uint32_t lat_rounds,
@@ -1285,7 +1304,7 @@ void demod_kernel( const DevCfg *__restrict__ cfgp, const double *__restrict__ t
 	__builtin_amdgcn_s_setprio(3);
 	master_loop<USE_SLAB>(cfg, tw, io, slab_cap, lat_frames * lat_rounds, lat_frames, lat_mode, base0, lds);
     } else {
-	worker_main<USE_SLAB>(cfgp, tw, lds, io.d_samples + (size_t)blockIdx.x * io.stream_stride,
+	worker_main<USE_SLAB, NQ>(cfgp, tw, lds, io.d_samples + (size_t)blockIdx.x * io.stream_stride,
 			      n_own, slab_cap, lat_frames, region_floats, region_cap, lat_mode, safe_limit,
 			      io.d_counters ? io.d_counters + (size_t)blockIdx.x * MIFSK_NCOUNTERS : nullptr);
     }
@@ -1442,16 +1461,24 @@ int launch_demod_batch( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_
     hipStream_t st = (hipStream_t)stream;
     if ( use_slab ) {
 	const size_t lds_bytes = kLdsHeader + slab_floats * 4;
+	// (per-stream tone tables, --auto-carrier, keep the scalar-cache correlator)
+	const bool bell202 = lat_mode == LAT_LINEAR && B == 40u && !d_tw_v;
 	hipError_t e = hipFuncSetAttribute(
-		reinterpret_cast<const void *>(&demod_kernel<true>),
+		bell202 ? reinterpret_cast<const void *>(&demod_kernel<true, 10>)
+			: reinterpret_cast<const void *>(&demod_kernel<true, 0>),
 		hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 	if ( e != hipSuccess )
 	    return hip_rc(e);
-	hipLaunchKernelGGL(demod_kernel<true>, dim3((unsigned)io.nstreams), dim3(BLOCK),
-			   lds_bytes, st, d_cfg, d_tw, io, slab_cap, lat_frames, lat_rounds,
-			   (uint32_t)region_floats, region_cap, lat_mode, d_tw_v, d_start_v);
+	if ( bell202 )
+	    hipLaunchKernelGGL((demod_kernel<true, 10>), dim3((unsigned)io.nstreams), dim3(BLOCK),
+			       lds_bytes, st, d_cfg, d_tw, io, slab_cap, lat_frames, lat_rounds,
+			       (uint32_t)region_floats, region_cap, lat_mode, d_tw_v, d_start_v);
+	else
+	    hipLaunchKernelGGL((demod_kernel<true, 0>), dim3((unsigned)io.nstreams), dim3(BLOCK),
+			       lds_bytes, st, d_cfg, d_tw, io, slab_cap, lat_frames, lat_rounds,
+			       (uint32_t)region_floats, region_cap, lat_mode, d_tw_v, d_start_v);
     } else {
-	hipLaunchKernelGGL(demod_kernel<false>, dim3((unsigned)io.nstreams), dim3(BLOCK),
+	hipLaunchKernelGGL((demod_kernel<false, 0>), dim3((unsigned)io.nstreams), dim3(BLOCK),
 			   kLdsHeader + 16, st, d_cfg, d_tw, io, 0u, 0u, 1u, 0u, 0u, (uint32_t)LAT_NONE,
 			   d_tw_v, d_start_v);
     }

@@ -152,7 +152,7 @@ struct Wave {
     TwGroup		tgr[3];
     // counters
     uint32_t		n_blocks, n_scans, n_positions, n_hits, n_stages;
-    uint32_t		cyc_block, cyc_scan;
+    uint32_t		cyc_block, cyc_scan, cyc_stage, cyc_corr, cyc_conf;
 
     __device__ __forceinline__ Wave( const DevCfg &c, const WaveGeom &gg, const double *t,
 	    const float *xs, uint32_t n, float2 *m, float *s, float *r, uint32_t safe )
@@ -160,7 +160,7 @@ struct Wave {
 	  safe_limit(safe), slab_lo(0), slab_hi(0), l_conf(0.0f), l_ampl(0.0f), l_bits(0),
 	  lat_n(0), lat_anchor(0), spec(gg.lat_fmin), run(0), cold(0), pause(0),
 	  pref_lo(0xFFFFFFFFu), n_blocks(0), n_scans(0), n_positions(0), n_hits(0), n_stages(0),
-	  cyc_block(0), cyc_scan(0)
+	  cyc_block(0), cyc_scan(0), cyc_stage(0), cyc_corr(0), cyc_conf(0)
     {
 #pragma unroll
 	for ( int i = 0; i < SV; i++ )
@@ -218,6 +218,7 @@ struct Wave {
     __device__ __forceinline__ void round_linear( uint32_t A, uint32_t w0, uint32_t nw, uint32_t next_lo )
     {
 	const uint32_t B = cfg.bit_nsamples;
+	const uint32_t t_in = MIFSK_WCLOCK();
 	const uint32_t lo = A + win_rel(w0);			// uniform
 	// Raw loads of one round: 64 * SV consecutive float4 from sample
 	// `from`, whatever the round really needs -- no per-lane bounds logic.
@@ -267,22 +268,41 @@ struct Wave {
 	    pref_lo = ok ? next_lo : 0xFFFFFFFFu;
 	}
 	wave_lds_sync();
+	const uint32_t t_mid = MIFSK_WCLOCK();
+	cyc_stage += t_mid - t_in;
 	const uint32_t nq = B >> 2;				// (linear: B % 4 == 0; == NQ when NQ > 0)
-	for ( uint32_t s0 = 0; s0 < nw; s0 += 64u ) {
-	    const uint32_t w = w0 + s0 + lane;
-	    const bool active = s0 + lane < nw;
-	    const uint32_t rel = A + win_rel(active ? w : w0) - lo;	// idle lanes shadow the first window
-	    double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
-	    const float *p = slab + rel;
-	    if constexpr ( NQ > 0 )
-		corr_lds_fixed<NQ>(tgr, p, acc);		// the instantiation for this bit length
-	    else
-		corr_lds_stream(tw, p, nq, lane, acc);
-	    if ( active )
-		mags[w] = make_float2(band_mag(acc[0], acc[1], cfg.magscalar),
-				      band_mag(acc[2], acc[3], cfg.magscalar));
+	if constexpr ( NQ > 0 ) {
+	    // the instantiation for this bit length: table resident, two windows
+	    // per lane (w and w + 64) for eight independent FMA chains
+	    for ( uint32_t s0 = 0; s0 < nw; s0 += 128u ) {
+		const uint32_t wa = w0 + s0 + lane, wb = wa + 64u;
+		const bool act_a = s0 + lane < nw, act_b = s0 + 64u + lane < nw;
+		// idle lanes shadow the round's first window
+		const uint32_t rel_a = A + win_rel(act_a ? wa : w0) - lo;
+		const uint32_t rel_b = A + win_rel(act_b ? wb : w0) - lo;
+		double acc_a[4] = { 0.0, 0.0, 0.0, 0.0 }, acc_b[4] = { 0.0, 0.0, 0.0, 0.0 };
+		corr_lds_fixed2<NQ>(tgr, slab + rel_a, slab + rel_b, acc_a, acc_b);
+		if ( act_a )
+		    mags[wa] = make_float2(band_mag(acc_a[0], acc_a[1], cfg.magscalar),
+					   band_mag(acc_a[2], acc_a[3], cfg.magscalar));
+		if ( act_b )
+		    mags[wb] = make_float2(band_mag(acc_b[0], acc_b[1], cfg.magscalar),
+					   band_mag(acc_b[2], acc_b[3], cfg.magscalar));
+	    }
+	} else {
+	    for ( uint32_t s0 = 0; s0 < nw; s0 += 64u ) {
+		const uint32_t w = w0 + s0 + lane;
+		const bool active = s0 + lane < nw;
+		const uint32_t rel = A + win_rel(active ? w : w0) - lo;	// idle lanes shadow the first window
+		double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
+		corr_lds_stream(tw, slab + rel, nq, lane, acc);
+		if ( active )
+		    mags[w] = make_float2(band_mag(acc[0], acc[1], cfg.magscalar),
+					  band_mag(acc[2], acc[3], cfg.magscalar));
+	    }
 	}
 	wave_lds_sync();			// the slab is rewritten by the next round
+	cyc_corr += MIFSK_WCLOCK() - t_mid;
     }
 
     // LATTICE, direct variant: any bit length, no LDS staging.  One lane per bit
@@ -337,6 +357,7 @@ struct Wave {
 	    wave_lds_sync();
 	}
 	// score: lane f = frame f (fsk.c:178-446 after the magnitudes)
+	const uint32_t t_cf = MIFSK_WCLOCK();
 	FrameOut fo;
 	fo.conf = 0.0f; fo.ampl = 0.0f; fo.bits = 0;
 	if ( lane < F ) {
@@ -351,6 +372,7 @@ struct Wave {
 	slab_lo = slab_hi = 0;			// the rounds overwrote whatever SCAN had staged
 	wave_lds_sync();
 	n_blocks++;
+	cyc_conf += MIFSK_WCLOCK() - t_cf;
 	cyc_block += MIFSK_WCLOCK() - t0;
     }
 
@@ -552,7 +574,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char mifsk_wave_smem[];
 // (the wide-staging instantiation runs where a wave has >= 10 KiB of LDS to
 // itself, i.e. at most 2-3 waves per SIMD: it may use 256 VGPRs)
 template <int SV, int NQ>
-__global__ __launch_bounds__(64, SV >= 10 ? 2 : 4)
+__global__ __launch_bounds__(64, SV >= 20 ? 1 : SV >= 10 ? 2 : 4)
 void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restrict__ tw_default,
 	mifsk_demod_io io, WaveGeom g, WaveAuto au )
 {
@@ -620,6 +642,7 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
     uint32_t n_out_frames = 0, n_out_bytes = 0, n_out_eps = 0, ep_first = 0, ep_b_mark = 0;
     uint32_t status = 0;
     uint32_t n_iter = 0, n_bulk = 0, n_refine = 0, n_detect = 0;
+    uint32_t cyc_bulk = 0, cyc_general = 0;
     const uint32_t t_start = MIFSK_WCLOCK();
 
     const ZigZag zc0(cfg.try_first[0], cfg.try_max[0], cfg.try_step[0]);
@@ -651,6 +674,7 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 	// launcher enables the lattice only for such geometries.)
 	// ------------------------------------------------------------------
 	if ( lattice_ok && carrier && advance && advance <= N - base ) {
+	    const uint32_t t_bulk = MIFSK_WCLOCK();
 	    const uint32_t first = cfg.try_first[1];
 	    const uint32_t nb = base + advance;		// cursor of the next iteration
 	    const uint32_t p = nb + first;
@@ -779,9 +803,11 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 		    progressed = true;
 		}
 	    }
+	    cyc_bulk += MIFSK_WCLOCK() - t_bulk;	// (block evaluation included)
 	    if ( progressed )
 		continue;
 	}
+	const uint32_t t_gen = MIFSK_WCLOCK();
 
 	// ------------------------------------------------------------------
 	// one iteration of the reference's loop
@@ -992,6 +1018,7 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 	    n_out_bytes++;
 	if ( ctx.pause )
 	    ctx.pause--;
+	cyc_general += MIFSK_WCLOCK() - t_gen;
     }
 
     if ( carrier ) {						// minimodem.c:1469-1474
@@ -1033,6 +1060,11 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 	    c[MIFSK_CNT_CYC_TOTAL] = MIFSK_WCLOCK() - t_start;
 	    c[MIFSK_CNT_CYC_PARALLEL] = ctx.cyc_scan;
 	    c[MIFSK_CNT_CYC_WAIT] = ctx.cyc_block;
+	    c[MIFSK_CNT_CYC_CONFIDENCE] = ctx.cyc_conf;
+	    c[MIFSK_CNT_CYC_BULK] = cyc_bulk;
+	    c[13] = ctx.cyc_stage;
+	    c[14] = ctx.cyc_corr;
+	    c[16] = cyc_general;
 	    c[22] = n_detect;
 	}
     }
@@ -1165,14 +1197,7 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
 {
     if ( io.nstreams <= 0 )
 	return 0;
-    int ncu = 256;
-    {
-	int dev = 0;
-	hipDeviceProp_t prop;
-	if ( hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess
-		&& prop.multiProcessorCount > 0 )
-	    ncu = prop.multiProcessorCount;
-    }
+    const int ncu = ha.ncu > 0 ? ha.ncu : 256;
     // Waves per CU the batch can use (a wave is a workgroup): at least one per
     // SIMD, at most 16 (4 per SIMD at <= 128 VGPRs).  Each gets that share of
     // the CU's LDS; prefer the widest staging that fits, then fewer waves.
@@ -1181,9 +1206,14 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
     if ( want > 16u ) want = 16u;
     Plan plan;
     bool ok = false;
+    // bit lengths with a resident-table instantiation at the widest staging
+    const bool wide_ok = cfg.lat_linear && ( cfg.bit_nsamples == 40u || cfg.bit_nsamples == 20u );
     for ( uint32_t wpc = want; wpc >= 4u && !ok; wpc -= ( wpc > 8u ? 4u : ( wpc > 4u ? 2u : 1u ) ) ) {
 	const size_t budget = ( kLdsPerCu / wpc ) & ~(size_t)255;
-	ok = plan_for(cfg, ha, 10, budget, plan) && plan.g.slab_cap != 0u;
+	// widest staging first (two windows per lane want 128-window rounds)
+	ok = wide_ok && plan_for(cfg, ha, 20, budget, plan) && plan.g.slab_cap != 0u;
+	if ( !ok )
+	    ok = plan_for(cfg, ha, 10, budget, plan) && plan.g.slab_cap != 0u;
 	if ( !ok )
 	    ok = plan_for(cfg, ha, 4, budget, plan) && plan.g.slab_cap != 0u;
 	if ( wpc == 4u )
@@ -1226,13 +1256,15 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
 	hipLaunchKernelGGL((demod_wave_kernel<SV_, NQ_>), dim3((unsigned)io.nstreams), dim3(64),		\
 			   plan.lds_bytes, st, d_cfg, d_tw, io, g, au);						\
     } while (0)
-    if ( plan.sv == 10 ) {
-	if ( nq == 10u )     MIFSK_WAVE_LAUNCH(10, 10);		// 1200 baud at 48 kHz
-	else if ( nq == 5u ) MIFSK_WAVE_LAUNCH(10, 5);		// 2400 baud; 1200 baud at 24 kHz
+    if ( plan.sv == 20 ) {
+	if ( nq == 10u )     MIFSK_WAVE_LAUNCH(20, 10);		// 1200 baud at 48 kHz
+	else                 MIFSK_WAVE_LAUNCH(20, 5);		// 2400 baud; 1200 baud at 24 kHz
+    } else if ( plan.sv == 10 ) {
+	if ( nq == 10u )     MIFSK_WAVE_LAUNCH(10, 10);
+	else if ( nq == 5u ) MIFSK_WAVE_LAUNCH(10, 5);
 	else                 MIFSK_WAVE_LAUNCH(10, 0);
     } else {
-	if ( nq == 10u )     MIFSK_WAVE_LAUNCH(4, 10);
-	else if ( nq == 1u ) MIFSK_WAVE_LAUNCH(4, 1);		// 12000 baud
+	if ( nq == 1u )      MIFSK_WAVE_LAUNCH(4, 1);		// 12000 baud
 	else                 MIFSK_WAVE_LAUNCH(4, 0);
     }
 #undef MIFSK_WAVE_LAUNCH

@@ -24,6 +24,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 import _oracle as O  # noqa: E402
 
 ASCII_PAYLOAD = (b"The quick brown fox jumps over the lazy dog 0123456789 "
@@ -98,6 +99,56 @@ CASES = [
      ["--Xrxnoise", "0.50", "1200"], dict(baudmode="1200")),
     ("t91_print_filter", b"tab\there \x01\x02 bell\x07 del\x7f high\xe9\xff nl\n cr\r end",
      ["1200"], ["1200", "--print-filter"], dict(baudmode="1200")),
+    # ---- round 2: the reference tests that had no recording of their own --------------
+    # tests/04-self-test-0.5.test: 96000-sample bit windows, 6.1 M samples.  Stored as payload +
+    # SHA-256 of the reference's samples; the loader regenerates them with the host transmitter
+    # (bit-exact with the reference's WAV: tests/test_tx_synth.py) and checks the hash.
+    ("t04_0p5", b"KAMAL\n", ["0.5"], ["0.5"], dict(baudmode="0.5"), dict(regen=True)),
+    ("t09_1200_lut16_float", ASCII_PAYLOAD, ["1200", "--lut=16", "--float-samples"], ["1200"],
+     dict(baudmode="1200")),
+    ("t11_perfect_nolut", ASCII_PAYLOAD,
+     "1200 --samplerate 24000 -M 1200 -S 2400 --lut=0".split(),
+     "1200 --samplerate 24000 -M 1200 -S 2400".split(),
+     dict(baudmode="1200", sample_rate=24000, mark_f=1200, space_f=2400)),
+    ("t12_perfect_lut16", ASCII_PAYLOAD,
+     "1200 --samplerate 24000 -M 1200 -S 2400 --lut=16".split(),
+     "1200 --samplerate 24000 -M 1200 -S 2400".split(),
+     dict(baudmode="1200", sample_rate=24000, mark_f=1200, space_f=2400)),
+    ("t15_perfect_float", ASCII_PAYLOAD,
+     "1200 --samplerate 24000 -M 1200 -S 2400 --float-samples".split(),
+     "1200 --samplerate 24000 -M 1200 -S 2400".split(),
+     dict(baudmode="1200", sample_rate=24000, mark_f=1200, space_f=2400)),
+    # tests/30-amplitude.test / 31-amplitude-float.test: clipping S16 at volume 3.5, unclipped
+    # float at 3.5, the 0.01 floor
+    ("t30_ampl_3p50", ASCII_PAYLOAD[:48], ["--volume", "3.50", "1200"], ["1200"], dict(baudmode="1200")),
+    ("t30_ampl_0p01", ASCII_PAYLOAD[:48], ["--volume", "0.01", "1200"], ["1200"], dict(baudmode="1200")),
+    ("t31_ampl_float_3p50", ASCII_PAYLOAD[:48], ["--volume", "3.50", "1200", "--float-samples"],
+     ["1200"], dict(baudmode="1200")),
+    ("t31_ampl_float_0p01", ASCII_PAYLOAD[:48], ["--volume", "0.01", "1200", "--float-samples"],
+     ["1200"], dict(baudmode="1200")),
+    # tests/40-noise.test and 41-noise-purefreqs.test as they are run: --volume 0.5, --rx-one
+    ("t40_rxnoise_0p05_rxone", ASCII_PAYLOAD[:40], ["1200", "--volume", "0.5"],
+     ["1200", "--Xrxnoise", "0.05", "--rx-one"], dict(baudmode="1200", rx_one=1)),
+    ("t41_purefreqs_0p50_rxone", ASCII_PAYLOAD[:40], ["1200", "-M", "1200", "-S", "2400", "--volume", "0.5"],
+     ["1200", "-M", "1200", "-S", "2400", "--Xrxnoise", "0.50", "--rx-one"],
+     dict(baudmode="1200", mark_f=1200, space_f=2400, rx_one=1)),
+    ("t41_purefreqs_0p00_rxone", ASCII_PAYLOAD[:40], ["1200", "-M", "1200", "-S", "2400", "--volume", "0.5"],
+     ["1200", "-M", "1200", "-S", "2400", "--Xrxnoise", "0.00", "--rx-one"],
+     dict(baudmode="1200", mark_f=1200, space_f=2400, rx_one=1)),
+    # --auto-carrier re-detection (minimodem.c:1297: the band is dropped after 21 searches without
+    # confidence): noise above the detection threshold before the signal -- the reference locks onto
+    # a noise band first and has to recover --, and two bursts on different tone pairs
+    ("t51_auto_300_noise_lead", ASCII_PAYLOAD[:24], None, ["--auto-carrier", "300"],
+     dict(baudmode="300", auto_carrier_threshold=0.001),
+     dict(compose=[("noise", 9000, 0.02, 7), ("tx", ["300"], ASCII_PAYLOAD[:24]), ("silence", 3000)])),
+    ("t51_auto_300_two_bursts", ASCII_PAYLOAD[:24] + ASCII_PAYLOAD[24:40], None, ["--auto-carrier", "300"],
+     dict(baudmode="300", auto_carrier_threshold=0.001),
+     dict(compose=[("silence", 2000), ("tx", ["300"], ASCII_PAYLOAD[:24]), ("silence", 20011),
+                   ("tx", ["300", "-M", "1870", "-S", "1670"], ASCII_PAYLOAD[24:40]), ("silence", 5000)])),
+    ("t51_auto_1200_two_bursts_noise", ASCII_PAYLOAD[:30] + ASCII_PAYLOAD[30:60], None, ["--auto-carrier", "1200"],
+     dict(baudmode="1200", auto_carrier_threshold=0.001),
+     dict(compose=[("noise", 4000, 0.004, 3), ("tx", ["1200"], ASCII_PAYLOAD[:30]), ("noise", 9000, 0.004, 4),
+                   ("tx", ["1200", "-M", "1600", "-S", "2600"], ASCII_PAYLOAD[30:60]), ("silence", 2500)])),
 ]
 
 
@@ -136,14 +187,49 @@ def find_frame_trace(cfg, x, max_calls=24):
     return np.array(rows, dtype=dt)
 
 
+def compose_wav(parts, wav):
+    """A recording made of reference transmissions, silence and (seeded) noise, written as S16
+    the way the reference writes its files."""
+    chunks, sr = [], None
+    for part in parts:
+        if part[0] == "tx":
+            tmp = O.tmp_wav()
+            try:
+                O.ref_tx(part[2], part[1], tmp)
+                with open(tmp, "rb") as f:
+                    raw = f.read()
+                sr0, _ = O.read_wav(tmp)
+            finally:
+                os.unlink(tmp)
+            assert sr in (None, sr0)
+            sr = sr0
+            chunks.append(np.frombuffer(raw[44:], dtype="<i2").copy())
+        elif part[0] == "silence":
+            chunks.append(np.zeros(part[1], "<i2"))
+        elif part[0] == "noise":
+            rng = np.random.default_rng(part[3])
+            chunks.append(np.clip(np.rint(rng.normal(0, part[2], part[1]) * 32768), -32768, 32767).astype("<i2"))
+        else:
+            raise ValueError(part[0])
+    O.write_wav(wav, np.concatenate(chunks), sr, True)
+
+
 def main():
+    import hashlib
+    only = set(sys.argv[1:])
     assert O.have_ref(), "oracle/_ref missing: run `make -C oracle` where /root/reference exists"
     for case in CASES:
         name, payload, tx, rx, kw = case[:5]
+        if only and name not in only:
+            continue
         extra = case[5] if len(case) > 5 else {}
         wav = O.tmp_wav()
         try:
-            O.ref_tx(payload, tx, wav)
+            if extra.get("compose"):
+                compose_wav(extra["compose"], wav)
+                tx = ["(composed)"]
+            else:
+                O.ref_tx(payload, tx, wav)
             if extra.get("lead"):       # leading silence: rewrite the reference's file
                 with open(wav, "rb") as f:
                     raw0 = f.read()
@@ -177,8 +263,19 @@ def main():
         stats = [l for l in err.splitlines() if l.startswith("### NOCARRIER")]
         carriers = [l for l in err.splitlines() if l.startswith("### CARRIER")]
         path = os.path.join(HERE, name + ".npz")
+        regen = {}
+        if extra.get("regen"):
+            # too long to store: keep the hash and the transmitter's arguments instead
+            import minimodem_amd as M
+            mine = M.synthesize(M.rx_config(**kw), payload, s16=not is_float)
+            assert np.array_equal(mine, x), "host transmitter differs from the reference's WAV"
+            regen = dict(samples_sha256=np.array(hashlib.sha256(stored.tobytes()).hexdigest()),
+                         samples_len=np.int64(stored.shape[0]),
+                         samples_dtype=np.array(stored.dtype.str))
+            trace = trace[:6]
+            stored = stored[:0]
         np.savez_compressed(
-            path, samples=stored, sample_rate=np.int64(sr),
+            path, samples=stored, sample_rate=np.int64(sr), **regen,
             payload=np.frombuffer(payload, np.uint8),
             stdout=np.frombuffer(out, np.uint8),
             nocarrier=np.array(stats), carrier=np.array(carriers),
