@@ -78,55 +78,94 @@ def test_config4_12000_baud_8192_streams(gpu):
         assert O.oracle_rx_stream(ocfg, host[i])["bytes"] == payloads[i].tobytes()
 
 
-def test_config3_rtty_long_windows(gpu):
-    """BASELINE configs[2] shape (1056-sample bit windows), reduced stream count."""
+def _device_batch(M, torch, ctx, cfg, nstreams, seconds, seed, lo, hi, amplitude=1.0, max_lead=40):
+    """A BASELINE-sized batch generated on the device (mifsk_tx_synthesize_batch is pinned
+    bit-for-bit to the reference's transmitter by tests/test_gpu_txdev.py): random words, 0..40
+    samples of leading silence per stream.  Returns (samples, lengths, words on the host)."""
+    rng = np.random.default_rng(seed)
+    nsamp = int(seconds * cfg.sample_rate)
+    frame = (cfg.n_data_bits + cfg.nstartbits + cfg.nstopbits) * cfg.nsamples_per_bit
+    nwords = int((nsamp - 6 * cfg.nsamples_per_bit - 41 - (16 * frame if cfg.do_rx_sync else 0)) / frame) - 2
+    words = rng.integers(lo, hi, size=(nstreams, nwords), dtype=np.uint8)
+    lead = torch.from_numpy(rng.integers(0, max_lead + 1, size=nstreams).astype(np.int32)).cuda()
+    stride = (nsamp + 3) & ~3
+    x, n = M.synthesize_batch(ctx, cfg, torch.from_numpy(words).cuda(), stride=stride,
+                              leading_silence=lead, amplitude=amplitude)
+    assert int(n.max()) <= stride
+    return x, n, words
+
+
+def _assert_sampled_streams_equal_oracle(res, x, n, ocfg, sample, what=("bits", "start", "flags")):
+    """Frame-for-frame equality with the oracle (bits, starts, flags, confidence and amplitude
+    bit patterns, episodes) on the sampled streams."""
+    for i in sample:
+        xi = x[i, :int(n[i])].cpu().numpy()
+        ref = O.oracle_rx_stream(ocfg, xi)
+        nf = int(res["nframes"][i])
+        assert nf == len(ref["frames"]), (i, nf, len(ref["frames"]))
+        assert res["frames"][i, :nf].tobytes() == ref["frames"].tobytes(), i
+        ne = int(res["nepisodes"][i])
+        assert ne == len(ref["episodes"]), (i, ne)
+        m = min(ne, res["episodes"].shape[1])
+        assert res["episodes"][i, :m].tobytes() == ref["episodes"][:m].tobytes(), i
+
+
+def test_config3_rtty_4096_streams_x_30s(gpu):
+    """BASELINE configs[2] at its stated size: RTTY 45.45 baud (1056-sample bit windows),
+    4096 streams x 30 s = 23.6 GB resident.  Every stream's 5-bit words must come back as
+    transmitted; 64 streams spread over the batch are compared frame for frame with the oracle."""
     M, torch, ctx = gpu
     cfg = M.rx_config("rtty")
-    host, payloads = _batch(M, cfg, 128, 60, seed=3, lo=0, hi=32)
-    res = _run(M, torch, ctx, cfg, host, want=("bits", "episodes"))
-    ocfg = O.oracle_config("rtty")
-    for i in range(0, 128, 9):
-        ref = O.oracle_rx_stream(ocfg, host[i])
-        nf = int(res["nframes"][i])
-        assert nf == len(ref["frames"]) >= 58
-        assert np.array_equal(res["bits"][i, :nf], ref["frames"]["bits"])
-    # 5-bit words come back as transmitted (the frame before the first one may be the leader)
-    for i in range(128):
+    x, n, words = _device_batch(M, torch, ctx, cfg, 4096, 30.0, seed=3, lo=0, hi=32)
+    out = M.demod_batch(ctx, cfg, x, nsamples=n, want=("bits", "frames", "episodes"), episodes_cap=4)
+    torch.cuda.synchronize()
+    res = M.results_to_host(out)
+    for i in range(4096):
         nf = int(res["nframes"][i])
         got = res["bits"][i, :nf].astype(np.uint8)
-        assert bytes(payloads[i]) in bytes(got), i
+        assert words[i].tobytes() in got.tobytes(), i
+    _assert_sampled_streams_equal_oracle(res, x, n, O.oracle_config("rtty"), range(0, 4096, 64))
+    del x, out
+    torch.cuda.empty_cache()
 
 
-def test_config5_same_with_noise_sweep(gpu):
-    """BASELINE configs[4] shape: NOAA SAME, amplitude 0.5, AWGN SNR sweep; decode
-    must equal the oracle's on identical buffers at every SNR (whether or not the
-    payload survives), plus the reference's DC-offset sweep (tests/40-noise.test)."""
+def test_config5_same_8192_streams_x_10s_noise_sweep(gpu):
+    """BASELINE configs[4] at one GPU's size: NOAA SAME, 8192 streams x 10 s, amplitude 0.5,
+    AWGN at SNR inf / 20 / 12 / 9 / 6 / 3 dB plus the reference's DC-offset sweep
+    (tests/40-noise.test), conditions interleaved over the batch.  72 sampled streams (nine
+    per condition) are compared frame for frame with the oracle on identical buffers --
+    whether or not the payload survives the noise -- and the clean and DC-offset streams must
+    decode their payload."""
     M, torch, ctx = gpu
     cfg = M.rx_config("same")
-    ocfg = O.oracle_config("same")
-    rng = np.random.default_rng(11)
-    host, payloads = _batch(M, cfg, 48, 40, seed=5)
-    host *= np.float32(0.5)
+    # (no leading silence: SAME frames have no start/stop bits, and the reference's byte
+    # alignment on the 0xAB preamble only holds when the stream starts on a bit boundary --
+    # with a few samples of silence in front it decodes 0xD5 0xD5 ... and shifted payloads,
+    # on the CPU just the same)
+    x, n, words = _device_batch(M, torch, ctx, cfg, 8192, 10.0, seed=5, lo=32, hi=127, amplitude=0.5,
+                                max_lead=0)
     p_sig = 0.5 ** 2 / 2
-    noisy = host.copy()
-    labels = []
-    for i in range(48):
-        kind = i % 8
-        if kind < 6:
-            snr_db = [None, 20, 12, 9, 6, 3][kind]
-            if snr_db is not None:
-                sigma = np.sqrt(p_sig / 10 ** (snr_db / 10))
-                noisy[i] += rng.normal(0, sigma, noisy.shape[1]).astype(np.float32)
-            labels.append(("snr", snr_db))
-        else:
-            dc = [0.05, 0.50][kind - 6]
-            noisy[i] -= np.float32(dc)
-            labels.append(("dc", dc))
-    res = _run(M, torch, ctx, cfg, noisy)
-    decoded_ok = 0
-    for i in range(48):
-        ref = O.oracle_rx_stream(ocfg, noisy[i])
+    conds = [("snr", None), ("snr", 20), ("snr", 12), ("snr", 9), ("snr", 6), ("snr", 3), ("dc", 0.05), ("dc", 0.50)]
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    for k, (kind, v) in enumerate(conds):
+        rows = x[k::8]
+        if kind == "snr" and v is not None:
+            sigma = float(np.sqrt(p_sig / 10 ** (v / 10)))
+            rows += torch.randn(rows.shape, generator=g, device="cuda", dtype=torch.float32) * sigma
+        elif kind == "dc":
+            rows -= np.float32(v)
+    out = M.demod_batch(ctx, cfg, x, nsamples=n, want=("bytes", "frames", "episodes"), episodes_cap=64)
+    torch.cuda.synchronize()
+    res = M.results_to_host(out)
+    ok = {k: 0 for k in range(8)}
+    for i in range(8192):
         nb = int(res["nbytes"][i])
-        assert res["bytes"][i, :nb].tobytes() == ref["bytes"], (i, labels[i])
-        decoded_ok += ref["bytes"] == payloads[i].tobytes()
-    assert decoded_ok >= 12		# at least the clean and the 20 dB streams
+        ok[i % 8] += words[i].tobytes() in res["bytes"][i, :nb].tobytes()
+    assert ok[0] == 1024 and ok[6] == 1024 and ok[7] == 1024, ok
+    assert ok[1] >= 800 and ok[5] <= ok[1], ok          # 20 dB mostly decodes; 3 dB does no better
+    sample = [k + 8 * j for k in range(8) for j in range(0, 1024, 114)]
+    assert len(sample) == 72
+    _assert_sampled_streams_equal_oracle(res, x, n, O.oracle_config("same"), sample)
+    del x, out
+    torch.cuda.empty_cache()
