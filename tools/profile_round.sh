@@ -1,23 +1,31 @@
 #!/bin/bash
 # Collect the round's profiling evidence on the GPU box (run through gpurun):
-#   tools/profile_round.sh r01
-# Writes under gpurun_out/profile_<tag>/ ; copy the summaries into profiles/.
+#   tools/profile_round.sh r02 "1200 rtty 12000 same"
+# Writes under gpurun_out/profile_<tag>_<config>/ ; tools/summarize_profile.py copies the
+# summaries into profiles/.  PMC counters are collected in their own passes with
+# --kernel-trace only (never together with other tracing domains).
 set -u
-TAG=${1:-r01}
-OUT=gpurun_out/profile_$TAG
-mkdir -p $OUT
+TAG=${1:-r02}
+CONFIGS=${2:-"1200 rtty 12000 same"}
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
-# 1. per-kernel time of the very command the bench line comes from
-timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o stats -- \
-    python bench.py --steps 20 --warmup 3 --no-cpu > $OUT/bench_under_rocprof.log 2>&1
-# 2. HBM traffic, separate PMC passes (no other tracing domains)
-timeout 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o fetch -- \
-    python bench.py --steps 5 --warmup 1 --no-cpu > $OUT/pmc_fetch.log 2>&1
-timeout 240 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT -o write -- \
-    python bench.py --steps 5 --warmup 1 --no-cpu > $OUT/pmc_write.log 2>&1
-# 3. instruction mix / VALU utilisation
-timeout 240 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY \
-    --output-format csv -d $OUT -o sq -- python bench.py --steps 5 --warmup 1 --no-cpu > $OUT/pmc_sq.log 2>&1
-# 4. the un-profiled bench line (with the CPU legs)
-timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err
-ls -la $OUT
+for C in $CONFIGS; do
+  OUT=gpurun_out/profile_${TAG}_$C
+  mkdir -p $OUT
+  B="python bench.py --config $C --no-cpu"
+  # 1. per-kernel time of the very command the bench line comes from
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o stats -- \
+      $B --steps 20 --warmup 3 > $OUT/bench_under_rocprof.log 2>&1
+  # 2. HBM traffic, separate PMC passes
+  timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o fetch -- \
+      $B --steps 4 --warmup 1 > $OUT/pmc_fetch.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT -o write -- \
+      $B --steps 4 --warmup 1 > $OUT/pmc_write.log 2>&1
+  # 3. instruction mix / occupancy / clock
+  timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY \
+      --output-format csv -d $OUT -o sq -- $B --steps 4 --warmup 1 > $OUT/pmc_sq.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY \
+      --output-format csv -d $OUT -o clk -- $B --steps 4 --warmup 1 > $OUT/pmc_clk.log 2>&1
+  # 4. the un-profiled bench line (with the CPU legs)
+  timeout 900 python bench.py --config $C > $OUT/bench.json 2> $OUT/bench.err
+  tail -c 600 $OUT/bench.json; echo
+done
