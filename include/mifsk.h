@@ -301,6 +301,11 @@ void mifsk_databits_reset( mifsk_databits *d );
 unsigned mifsk_databits_decode( mifsk_databits *d, char *out, unsigned out_size,
 	unsigned long long bits, unsigned n_databits );
 
+/* bfsk_databits_encode(words, c): the 1 or 2 data words character c is sent as
+ * (Baudot: a shift code first when needed; 0 = cannot be sent).  Transmit-side
+ * state (the Baudot shift) lives in the same object. */
+unsigned mifsk_databits_encode( mifsk_databits *d, unsigned *words_out /* [2] */, char c );
+
 #define MIFSK_TEXT_PRINT_FILTER	1u	/* -p, --print-filter (minimodem.c:1451-1460) */
 #define MIFSK_TEXT_QUIET	2u	/* -q, --quiet: no CARRIER / NOCARRIER lines  */
 

@@ -37,6 +37,43 @@ struct Baudot {
 	*out = charset == 1 ? kLetters[bits] : kFigures[bits];
 	return 1;
     }
+
+    // baudot_encode (baudot.c:249-311): the 5-bit word(s) for one character -- a
+    // shift code first when the character is not in the current set.  The
+    // reference's encode table is the inverse of the decode tables above, plus
+    // NUL (code 0, either set) and '+' (sent as 0x12 in figures).  Returns 0
+    // for a character that cannot be sent.
+    unsigned encode( unsigned *out, char ch )
+    {
+	int c = (unsigned char)ch;
+	if ( c >= 'a' && c <= 'z' )
+	    c -= 32;					// toupper, "C" locale
+	if ( c >= 0x60 || ch < 0 )
+	    return 0;
+	unsigned code = 0, mask = 0;
+	for ( unsigned k = 0; k < 32; k++ ) {
+	    if ( k == kLtrs || k == kFigs )
+		continue;
+	    if ( k != 0 && (unsigned char)kLetters[k] == c ) { mask |= 1u; code = k; }
+	    if ( k != 0 && (unsigned char)kFigures[k] == c ) { mask |= 2u; code = k; }
+	}
+	if ( c == 0 ) { mask = 3; code = 0; }
+	if ( c == '+' ) { mask = 2; code = 0x12; }
+	unsigned n = 0;
+	if ( ( charset & mask ) == 0 ) {
+	    if ( mask == 0 )
+		return 0;
+	    if ( charset == 0 )
+		charset = 1;
+	    if ( mask != 3 )
+		charset = mask;
+	    out[n++] = charset == 1 ? kLtrs : kFigs;
+	}
+	out[n++] = code;
+	if ( c == ' ' )
+	    charset = 1;				// TX un-shift on space
+	return n;
+    }
 };
 
 // ---- Caller-ID SDMF / MDMF -- databits_callerid.c ---------------------------
@@ -209,6 +246,23 @@ extern "C" void mifsk_databits_reset( mifsk_databits *d )
 	return;
     if ( d->decoder == MIFSK_DECODE_BAUDOT ) d->baudot.reset();	// databits_baudot.c:33-36
     if ( d->decoder == MIFSK_DECODE_CALLERID ) d->cid.reset();		// databits_callerid.c:164-165
+}
+
+// bfsk_databits_encode (databits.h:49-92): the data word(s) one input character
+// is transmitted as -- the byte itself (databits_ascii.c:118-124,
+// databits_binary.c), or Baudot with shift codes.  The caller-ID and UIC
+// decoders have no encoder in the reference either.
+extern "C" unsigned mifsk_databits_encode( mifsk_databits *d, unsigned *words_out, char c )
+{
+    if ( !d || !words_out )
+	return 0;
+    if ( d->decoder == MIFSK_DECODE_BAUDOT )
+	return d->baudot.encode(words_out, c);
+    if ( d->decoder == MIFSK_DECODE_ASCII8 || d->decoder == MIFSK_DECODE_BINARY ) {
+	words_out[0] = (unsigned char)c;
+	return 1;
+    }
+    return 0;
 }
 
 extern "C" unsigned mifsk_databits_decode( mifsk_databits *d, char *out, unsigned out_size,
