@@ -282,6 +282,21 @@ int mifsk_demod_batch( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
 int mifsk_demod_batch_host( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
 	const mifsk_demod_io *io );
 
+/* ---- several GPUs (SURVEY 8 e) -------------------------------------------- */
+
+/* Streams are independent: device k of `world` owns the contiguous, balanced
+ * range [*lo, *hi) of the batch.  The same arithmetic shards a multi-process
+ * job (one process per GPU; the decoded bytes are then gathered over RCCL). */
+void mifsk_shard_range( int nstreams, int rank, int world, int *lo, int *hi );
+
+/* mifsk_demod_batch_host over several devices of ONE process: ctxs[k] (one
+ * context per GPU, mifsk_ctx_create(&c, k)) takes range k of the batch; inputs
+ * are copied to, and every output array is filled from, the device that owns the
+ * stream -- no collective, the gather is the copy back.  Returns 0 or the first
+ * failing device's error. */
+int mifsk_demod_batch_host_multi( mifsk_ctx *const *ctxs, int nctx,
+	const mifsk_rx_config *cfg, const mifsk_demod_io *io );
+
 /* ---- host post-pass: frame bits -> text -------------------- */
 
 /* The databits decoders main() plugs in behind the search (databits.h:49-92:

@@ -520,7 +520,9 @@ def demod_batch_host(ctx, cfg, samples, nsamples=None, frames_cap=None, episodes
                      ring_exact=False):
     """mifsk_demod_batch_host: the whole batch from HOST memory in one call (copies
     in, runs the receive loop on the device, copies out, synchronises).  samples is a
-    float32 numpy array [nstreams, stride]; returns a dict of numpy arrays."""
+    float32 numpy array [nstreams, stride]; returns a dict of numpy arrays.
+    `ctx` may be a list of Contexts (one per GPU): mifsk_demod_batch_host_multi
+    shards the streams over them (mifsk_shard_range) inside this one process."""
     lib = _lib.load()
     samples = np.ascontiguousarray(samples, dtype=np.float32)
     nstreams, stride = samples.shape
@@ -557,7 +559,11 @@ def demod_batch_host(ctx, cfg, samples, nsamples=None, frames_cap=None, episodes
     io.d_status = res["status"].ctypes.data
     io.d_carrier_band = res["carrier_band"].ctypes.data
     io.flags = _lib.IO_RING_EXACT if ring_exact else 0
-    rc = lib.mifsk_demod_batch_host(ctx.handle, C.byref(cfg), C.byref(io))
+    if isinstance(ctx, (list, tuple)):
+        handles = (C.c_void_p * len(ctx))(*[c.handle for c in ctx])
+        rc = lib.mifsk_demod_batch_host_multi(handles, len(ctx), C.byref(cfg), C.byref(io))
+    else:
+        rc = lib.mifsk_demod_batch_host(ctx.handle, C.byref(cfg), C.byref(io))
     if rc != 0:
         raise RuntimeError("mifsk_demod_batch_host failed: %d" % rc)
     return res

@@ -169,7 +169,8 @@ EXPORTS = [
     "mifsk_demod_batch", "mifsk_demod_batch_host",
     "mifsk_tx_tone_init", "mifsk_tx_synthesize",
     "mifsk_databits_create", "mifsk_databits_destroy", "mifsk_databits_reset",
-    "mifsk_databits_decode", "mifsk_databits_encode", "mifsk_stream_text",
+    "mifsk_databits_decode", "mifsk_databits_encode", "mifsk_shard_range",
+    "mifsk_demod_batch_host_multi", "mifsk_stream_text",
     "mifsk_wav_parse", "mifsk_ingest_s16", "mifsk_ingest_rxnoise_f32",
     "mifsk_tx_synthesize_batch",
 ]

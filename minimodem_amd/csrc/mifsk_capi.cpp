@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "fsk.h"
@@ -497,6 +498,68 @@ extern "C" int mifsk_demod_batch_host( mifsk_ctx *ctx, const mifsk_rx_config *cf
     if ( hio->d_counters ) HIP_OK(hipMemcpy(hio->d_counters, d_cnt.p, ns * MIFSK_NCOUNTERS * sizeof(uint64_t), hipMemcpyDeviceToHost));
     if ( hio->d_carrier_band && cfg->auto_carrier_threshold > 0.0f )
 	HIP_OK(hipMemcpy(hio->d_carrier_band, d_band.p, ns * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// several devices, one process: streams are independent, so context k (one per
+// GPU) takes the contiguous range mifsk_shard_range(nstreams, k, nctx) and the
+// "gather" is each device's copy back into the caller's arrays -- no collective.
+// (One process per GPU with an RCCL gather of the decoded bytes is the other
+// arrangement: minimodem_amd.ByteGatherer, bench.py --gpus N.)
+// ---------------------------------------------------------------------------
+
+extern "C" void mifsk_shard_range( int nstreams, int rank, int world, int *lo, int *hi )
+{
+    if ( world <= 0 ) world = 1;
+    if ( nstreams < 0 ) nstreams = 0;
+    const int q = nstreams / world, r = nstreams % world;
+    const int a = rank * q + ( rank < r ? rank : r );
+    if ( lo ) *lo = a;
+    if ( hi ) *hi = a + q + ( rank < r ? 1 : 0 );
+}
+
+extern "C" int mifsk_demod_batch_host_multi( mifsk_ctx *const *ctxs, int nctx,
+	const mifsk_rx_config *cfg, const mifsk_demod_io *hio )
+{
+    if ( !ctxs || nctx <= 0 || !hio || hio->nstreams < 0 )
+	return -EINVAL;
+    for ( int k = 0; k < nctx; k++ )
+	if ( !ctxs[k] )
+	    return -EINVAL;
+    std::vector<int> rcs((size_t)nctx, 0);
+    std::vector<std::thread> workers;
+    for ( int k = 0; k < nctx; k++ ) {
+	int lo = 0, hi = 0;
+	mifsk_shard_range(hio->nstreams, k, nctx, &lo, &hi);
+	if ( hi == lo )
+	    continue;
+	mifsk_demod_io io = *hio;
+	const size_t o = (size_t)lo, fc = hio->frames_cap, ec = hio->episodes_cap;
+	io.nstreams = hi - lo;
+	io.d_samples = hio->d_samples + o * hio->stream_stride;
+	if ( io.d_nsamples )	 io.d_nsamples += o;
+	if ( io.d_bytes )	 io.d_bytes += o * fc;
+	if ( io.d_nbytes )	 io.d_nbytes += o;
+	if ( io.d_bits )	 io.d_bits += o * fc;
+	if ( io.d_frames )	 io.d_frames += o * fc;
+	if ( io.d_nframes )	 io.d_nframes += o;
+	if ( io.d_episodes )	 io.d_episodes += o * ec;
+	if ( io.d_nepisodes )	 io.d_nepisodes += o;
+	if ( io.d_status )	 io.d_status += o;
+	if ( io.d_counters )	 io.d_counters += o * MIFSK_NCOUNTERS;
+	if ( io.d_carrier_band ) io.d_carrier_band += o;
+	mifsk_ctx *ctx = ctxs[k];
+	int *rcp = &rcs[(size_t)k];
+	// one host thread per device: the HIP "current device" is per thread, so
+	// the per-device copies, launch and synchronisation proceed side by side
+	workers.emplace_back([ctx, cfg, io, rcp]() { *rcp = mifsk_demod_batch_host(ctx, cfg, &io); });
+    }
+    for ( std::thread &t : workers )
+	t.join();
+    for ( int rc : rcs )
+	if ( rc )
+	    return rc;
     return 0;
 }
 
