@@ -190,6 +190,8 @@ frame_confidence_any( const float2 *mags, uint64_t req_mask, uint64_t req_val, u
 	return frame_confidence_fixed<11>(mags, req_mask, req_val);
     if ( n_bits == 10u )
 	return frame_confidence_fixed<10>(mags, req_mask, req_val);
+    if ( n_bits == 8u )					// RTTY "10ddddd1", SAME "dddddddd"
+	return frame_confidence_fixed<8>(mags, req_mask, req_val);
     return frame_confidence(mags, req_mask, req_val, n_bits);
 }
 
@@ -532,6 +534,37 @@ __device__ __forceinline__ void replay_scan_asm( float &xt, float &xpk, float &x
 	: [cv] "v"(cv), [av] "v"(av)
 	: "scc");
 #undef MIFSK_SCAN_STEP
+}
+
+// The same lane scan for modes whose carrier-held search step is one sample
+// (12000 baud at 48 kHz): there "refine" is a flag and no search
+// (minimodem.c:1357 requires try_step_nsamples > 1), so a frame whose confidence
+// falls below 0.75 x the running peak is an ordinary frame with one side effect,
+//     peak_confidence = 0  (:1281)   and then   peak_confidence = confidence  (:1392-1393),
+// i.e. the peak recurrence is  pk <- (c < 0.75 pk) ? c : max(pk, c)  instead of a
+// plain running maximum.  Written with DPP moves under full EXEC and selects (no
+// branch on the lane: a lane whose source lane is masked off would not be
+// written); `steps` applications settle lanes 0 .. steps.
+__device__ __forceinline__ void replay_scan_soft( float &xt, float &xpk, float &xsc, float &xsa,
+	float &bt, float &bpk, float &bsc, float &bsa, float cv, float av, uint32_t K, uint32_t lane )
+{
+    const bool upper = lane > 0u;
+    for ( uint32_t step = 1; step < K; step++ ) {
+	const float pt = wave_shr1(xt), ppk = wave_shr1(xpk), psc = wave_shr1(xsc), psa = wave_shr1(xsa);
+	const float nt = ( pt + av ) / 2.0f;				// minimodem.c:1391
+	const float mx = ppk < cv ? cv : ppk;				// :1392-1393
+	const float npk = cv < ppk * 0.75f ? cv : mx;			// :1278-1281 first
+	xt = upper ? nt : xt;
+	xpk = upper ? npk : xpk;
+	xsc = upper ? psc + cv : xsc;					// :1397-1398
+	xsa = upper ? psa + av : xsa;
+    }
+    // the state BEFORE each lane's frame: the lower neighbour's "after" (lane 0 keeps the seed)
+    const float pt = wave_shr1(xt), ppk = wave_shr1(xpk), psc = wave_shr1(xsc), psa = wave_shr1(xsa);
+    bt = upper ? pt : bt;
+    bpk = upper ? ppk : bpk;
+    bsc = upper ? psc : bsc;
+    bsa = upper ? psa : bsa;
 }
 
 __device__ __forceinline__ float lane_bcast( float v, uint32_t src )
@@ -1016,24 +1049,39 @@ __device__ __forceinline__ void corr_skewed_stream( const DevCfg &cfg, const dou
     const uint32_t skew = cfg.skew;
     const uint32_t last = B - 1u;
     const uint32_t ng = ( B + 15u ) >> 4;
-    for ( uint32_t g = 0; g < ng; g++ ) {
-	const TwGroup G = tw_group_load(tw, g, lane);
+    TwGroup G = tw_group_load(tw, 0, lane);
+    // 16 samples of group g (clamped inside the window)
+#define MIFSK_SKEWED_LOAD(XS, GI)							\
+    _Pragma("unroll")									\
+    for ( int j = 0; j < 16; j++ ) {							\
+	uint32_t n = 16u * (GI) + (uint32_t)j;						\
+	n = n < last ? n : last;			/* (uniform) never past the window */	\
+	XS[j] = p[n + ( n >= wrap ? skew : 0u )];					\
+    }
+    // every group but the last with the next group's twiddles in flight; nothing
+    // is left outstanding at the end (see corr_lds_stream)
+    for ( uint32_t g = 0; g + 1u < ng; g++ ) {
+	const TwGroup Gn = tw_group_load(tw, g + 1u, lane);
 	float xs[16];
-#pragma unroll
-	for ( int j = 0; j < 16; j++ ) {
-	    uint32_t n = 16u * g + (uint32_t)j;
-	    n = n < last ? n : last;			// (uniform) never past the window
-	    xs[j] = p[n + ( n >= wrap ? skew : 0u )];
-	}
+	MIFSK_SKEWED_LOAD(xs, g)
+	dpp_settle();
+	group_bcast(acc, G, make_float4(xs[0], xs[1], xs[2], xs[3]), make_float4(xs[4], xs[5], xs[6], xs[7]),
+		    make_float4(xs[8], xs[9], xs[10], xs[11]), make_float4(xs[12], xs[13], xs[14], xs[15]));
+	G = Gn;
+    }
+    {
+	float xs[16];
+	MIFSK_SKEWED_LOAD(xs, ng - 1u)
 	const float4 s0 = make_float4(xs[0], xs[1], xs[2], xs[3]), s1 = make_float4(xs[4], xs[5], xs[6], xs[7]);
 	const float4 s2 = make_float4(xs[8], xs[9], xs[10], xs[11]), s3 = make_float4(xs[12], xs[13], xs[14], xs[15]);
-	const uint32_t left = B - 16u * g;
+	const uint32_t left = B - 16u * ( ng - 1u );
 	dpp_settle();
 	if ( left >= 16u )
 	    group_bcast(acc, G, s0, s1, s2, s3);
 	else
 	    group_bcast_tail(acc, G, s0, s1, s2, s3, left);
     }
+#undef MIFSK_SKEWED_LOAD
 }
 
 } // namespace mifsk

@@ -706,16 +706,25 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 		// Replay the f32 state recurrences over all K candidates as a lane
 		// scan (replay_scan_asm): lane k computes the state AFTER frame k by
 		// applying the reference's update to its lower neighbour's state.
+		// With a search step of one sample a "refine" is a flag and no search
+		// (minimodem.c:1357): the frame is an ordinary one whose only side
+		// effect is the reset of the running peak -- replayed as such.
+		const bool soft = cfg.try_step[1] <= 1u;
 		float xt = ( track_amplitude + av ) / 2.0f;		// minimodem.c:1391
 		float xpk = peak_confidence < cv ? cv : peak_confidence;	// :1392-1393
+		if ( soft && cv < peak_confidence * 0.75f )
+		    xpk = cv;						// :1278-1281, then :1392
 		float xsc = confidence_total + cv;			// :1397-1398
 		float xsa = amplitude_total + av;
 		float my_t = track_amplitude, my_pk = peak_confidence;
 		float my_sc = confidence_total, my_sa = amplitude_total;
-		replay_scan_asm(xt, xpk, xsc, xsa, my_t, my_pk, my_sc, my_sa, cv, av, K);
+		if ( soft )
+		    replay_scan_soft(xt, xpk, xsc, xsa, my_t, my_pk, my_sc, my_sa, cv, av, K, lane);
+		else
+		    replay_scan_asm(xt, xpk, xsc, xsa, my_t, my_pk, my_sc, my_sa, cv, av, K);
 		const bool ok = have
 		    && cv > 0.0f && cv >= cfg.search_limit	// fsk.c:492,499: first try ends the scan
-		    && !( cv < my_pk * 0.75f )			// minimodem.c:1278
+		    && ( soft || !( cv < my_pk * 0.75f ) )	// minimodem.c:1278
 		    && !( av < my_t * 0.25f )			// minimodem.c:1286
 		    && !( cv <= cfg.conf_threshold );		// minimodem.c:1292
 		const unsigned long long bad = __ballot(have && !ok);

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Print the kernel's per-stream work counters for the benchmark workload
-(diagnostic; run on the GPU box):  python tools/counters.py [--streams N]"""
+"""Print the kernel's per-stream work counters for a bench.py workload (diagnostic; run on the
+GPU box with the profile build):
+    MIFSK_LIBRARY=$PWD/minimodem_amd/libmifsk_prof.so python tools/counters.py --config same"""
 import argparse
 import os
 import sys
@@ -13,30 +14,48 @@ import bench  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--streams", type=int, default=1024)
-    ap.add_argument("--mode", default="1200")
+    ap.add_argument("--config", default="1200", choices=sorted(bench.WORKLOADS))
+    ap.add_argument("--streams", type=int, default=0)
+    ap.add_argument("--engine", default=None)
     args = ap.parse_args()
     import torch
     import minimodem_amd as M
     ctx = M.Context(0)
-    cfg = M.rx_config(args.mode)
-    host = np.zeros((args.streams, bench.NSAMPLES), np.float32)
-    for i in range(args.streams):
-        x, _ = bench.make_stream(M, cfg, i)
-        host[i, :len(x)] = x
-    d = torch.from_numpy(host).cuda()
+    entry, mode, per_gpu, seconds, _, amplitude = bench.WORKLOADS[args.config]
+    n = args.streams or per_gpu
+    cfg = M.rx_config(mode)
+    if args.config == "1200":
+        host = np.zeros((n, bench.NSAMPLES), np.float32)
+        for i in range(n):
+            x, _ = bench.make_stream(M, cfg, i)
+            host[i, :len(x)] = x
+        d, lens = torch.from_numpy(host).cuda(), None
+    else:
+        nsamp = int(seconds * cfg.sample_rate)
+        wl = [bench.stream_words(args.config, cfg, i, nsamp) for i in range(n)]
+        words = torch.from_numpy(np.stack([w for w, _ in wl])).cuda()
+        lead = torch.tensor([l for _, l in wl], dtype=torch.int32).cuda()
+        d, lens = M.synthesize_batch(ctx, cfg, words, stride=(nsamp + 3) & ~3, leading_silence=lead,
+                                     amplitude=amplitude)
     for _ in range(2):
-        out = M.demod_batch(ctx, cfg, d, want=("bytes", "counters"))
+        out = M.demod_batch(ctx, cfg, d, nsamples=lens, want=("bytes", "counters"), engine=args.engine)
     torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(); M.demod_batch(ctx, cfg, d, nsamples=lens, want=("bytes", "counters"), out=out, engine=args.engine); e1.record()
+        torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
     c = out["counters"].cpu().numpy().astype(np.float64)
     nf = out["nframes"].cpu().numpy()
-    print("streams %d  frames/stream mean %.1f" % (args.streams, nf.mean()))
+    print("%s: streams %d  frames/stream mean %.1f  kernel %.3f ms" % (args.config, n, nf.mean(), float(np.median(ts))))
     for idx, name in sorted(M.COUNTER_NAMES.items()):
         col = c[:, idx]
-        print("%-16s mean %12.1f  min %12.0f  max %12.0f" % (name, col.mean(), col.min(), col.max()))
+        if col.max() > 0:
+            print("%-16s mean %12.1f  min %12.0f  max %12.0f" % (name, col.mean(), col.min(), col.max()))
     tot = c[:, 8].mean()
-    for idx in (9, 10, 11, 12, 13, 14, 15):
-        print("  %-14s %5.1f%% of kernel cycles" % (M.COUNTER_NAMES[idx], 100 * c[:, idx].mean() / tot))
+    if tot > 0:
+        for idx in (9, 10, 11, 12, 13, 14, 16):
+            print("  %-14s %5.1f%% of the mean stream's cycles" % (M.COUNTER_NAMES[idx], 100 * c[:, idx].mean() / tot))
 
 
 if __name__ == "__main__":
