@@ -66,11 +66,8 @@ int launch_find_frame_batch( const DevCfg &cfg, const DevCfg *d_cfg, const doubl
 	const float *d_samples, const mifsk_search *d_problems,
 	mifsk_search_result *d_results, int nproblems, void *stream );
 
-// d_tw_v / d_start_v (both nullable): per-stream twiddle table and first cursor
-// (--auto-carrier); otherwise every stream uses d_tw and starts at sample 0
 int launch_demod_batch( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_tw,
-	const mifsk_demod_io &io, void *stream,
-	const double *const *d_tw_v = nullptr, const uint32_t *d_start_v = nullptr );
+	const mifsk_demod_io &io, void *stream );
 
 // ---- one wavefront per stream (mifsk_wave.hip) ---------------------------
 

@@ -322,30 +322,7 @@ __device__ __forceinline__ void store4_skewed( const DevCfg &cfg, float *slab, u
     }
 }
 
-// Twiddles of XCH = 8 consecutive samples (8 x 4 doubles = 64 SGPRs), fetched
-// through the scalar cache with all four loads in flight at once.  Inline asm
-// because the register allocator, left to itself in this large kernel, issues
-// them one at a time (load 16 SGPRs, wait, 8 FMAs, ...), which exposes the
-// scalar-memory latency four times per chunk.  The caller must execute
-// twiddle_wait() before touching the values.
 typedef double tw8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ void twiddle_fetch( const double *t, tw8 &a, tw8 &b, tw8 &c, tw8 &d )
-{
-    asm volatile("s_load_dwordx16 %0, %4, 0x0\n\t"
-		 "s_load_dwordx16 %1, %4, 0x40\n\t"
-		 "s_load_dwordx16 %2, %4, 0x80\n\t"
-		 "s_load_dwordx16 %3, %4, 0xc0"
-		 : "=&s"(a), "=&s"(b), "=&s"(c), "=&s"(d)
-		 : "s"(t)
-		 : "memory");
-}
-
-__device__ __forceinline__ void twiddle_wait()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-}
 
 #define MIFSK_FMA4(X, T, I)					\
     do {							\
@@ -355,61 +332,6 @@ __device__ __forceinline__ void twiddle_wait()
 	sr = fma(xd_, (T)[4 * (I) + 2], sr);			\
 	si = fma(xd_, (T)[4 * (I) + 3], si);			\
     } while (0)
-
-// The two-band correlation of ONE bit window held in a skewed slab (one lane).
-// `rel` is the window start relative to slab row 0.  The twiddle index is
-// uniform across the wave, so the twiddles arrive through the scalar cache; the
-// table is zero-padded to a multiple of XCH and the tail of the last chunk
-// contributes fma(x, 0, acc) == acc (its sample index is clamped so that it
-// never reads LDS that was not staged).
-static_assert(XCH == 8, "twiddle_fetch moves exactly 8 samples' worth");
-
-__device__ __forceinline__ void correlate_window( const DevCfg &cfg, const double *__restrict__ tw,
-	const float *slab, uint32_t rel, bool active, double acc[4] )
-{
-    const uint32_t B = cfg.bit_nsamples;
-    uint32_t row, col;
-    divmod_bit(cfg, rel, row, col);
-    const float *p = slab + rel + row * cfg.skew;
-    const uint32_t last = B - 1;
-    double mr = 0.0, mi = 0.0, sr = 0.0, si = 0.0;
-    if ( __all(!active || col == 0u) ) {
-	// every window of this wave starts on a row boundary: plain
-	// immediate-offset LDS reads, no per-sample address arithmetic
-	for ( uint32_t n0 = 0; n0 < B; n0 += XCH ) {
-	    tw8 ta, tb, tc, td;
-	    twiddle_fetch(tw + 4 * (size_t)n0, ta, tb, tc, td);
-	    float xs[XCH];
-#pragma unroll
-	    for ( int j = 0; j < XCH; j++ )
-		xs[j] = p[n0 + j < last ? n0 + j : last];
-	    twiddle_wait();
-	    MIFSK_FMA4(xs[0], ta, 0);  MIFSK_FMA4(xs[1], ta, 1);
-	    MIFSK_FMA4(xs[2], tb, 0);  MIFSK_FMA4(xs[3], tb, 1);
-	    MIFSK_FMA4(xs[4], tc, 0);  MIFSK_FMA4(xs[5], tc, 1);
-	    MIFSK_FMA4(xs[6], td, 0);  MIFSK_FMA4(xs[7], td, 1);
-	}
-    } else {
-	const uint32_t wrap = B - col;	// first n that falls into the next row
-	const uint32_t skew = cfg.skew;
-	for ( uint32_t n0 = 0; n0 < B; n0 += XCH ) {
-	    tw8 ta, tb, tc, td;
-	    twiddle_fetch(tw + 4 * (size_t)n0, ta, tb, tc, td);
-	    float xs[XCH];
-#pragma unroll
-	    for ( int j = 0; j < XCH; j++ ) {
-		const uint32_t n = n0 + j < last ? n0 + j : last;	// uniform
-		xs[j] = p[n + ( n >= wrap ? skew : 0u )];
-	    }
-	    twiddle_wait();
-	    MIFSK_FMA4(xs[0], ta, 0);  MIFSK_FMA4(xs[1], ta, 1);
-	    MIFSK_FMA4(xs[2], tb, 0);  MIFSK_FMA4(xs[3], tb, 1);
-	    MIFSK_FMA4(xs[4], tc, 0);  MIFSK_FMA4(xs[5], tc, 1);
-	    MIFSK_FMA4(xs[6], td, 0);  MIFSK_FMA4(xs[7], td, 1);
-	}
-    }
-    acc[0] = mr; acc[1] = mi; acc[2] = sr; acc[3] = si;
-}
 
 // Make this wave's LDS writes visible to its other lanes.  LDS operations of one
 // wave execute in order, so no hardware wait is needed; wavefront-scope fences
@@ -666,72 +588,6 @@ __device__ __forceinline__ void correlate_linear_asm( const double *tw, const fl
 	  "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v119", "v120", "v121");
 }
 
-// The same loop with HALF-chunk granularity (4 samples): `nhalf` >= 1 half chunks
-// are consumed, so a window of B samples costs ceil(B / 4) half chunks instead of
-// ceil(B / 8) whole ones -- at 12000 baud (B = 4) that halves the FMAs.  The
-// table must be readable one half chunk beyond the last one consumed (it is
-// padded by a whole chunk).  Same operations, same order.
-__device__ __forceinline__ void correlate_linear_asm_h( const double *tw, const float *p,
-	uint32_t nhalf, double &mr, double &mi, double &sr, double &si )
-{
-    const uint32_t tw_lo = (uint32_t)(uintptr_t)tw;
-    const uint32_t tw_hi = (uint32_t)( (uintptr_t)tw >> 32 );
-    const uint32_t addr = (uint32_t)(uintptr_t)(lds_cfloat *)p;
-    asm volatile(
-	"s_mov_b32 s34, %[tlo]\n\t"
-	"s_mov_b32 s35, %[thi]\n\t"
-	"s_mov_b32 s33, %[nh]\n\t"
-	"v_mov_b32_e32 v119, %[addr]\n\t"
-	"s_load_dwordx16 s[36:51], s[34:35], 0x0\n\t"
-	"s_load_dwordx16 s[52:67], s[34:35], 0x40\n\t"
-	"ds_read_b128 v[110:113], v119\n\t"
-	"1:\n\t"
-	"s_waitcnt lgkmcnt(0)\n\t"
-	"s_cmp_eq_u32 s33, 1\n\t"
-	"s_cbranch_scc1 3f\n\t"
-	"s_load_dwordx16 s[68:83], s[34:35], 0x80\n\t"
-	"s_load_dwordx16 s[84:99], s[34:35], 0xc0\n\t"
-	"ds_read_b128 v[114:117], v119 offset:16\n\t"
-	MIFSK_ASM_FMA4("v110", "s[36:37]", "s[38:39]", "s[40:41]", "s[42:43]")
-	MIFSK_ASM_FMA4("v111", "s[44:45]", "s[46:47]", "s[48:49]", "s[50:51]")
-	MIFSK_ASM_FMA4("v112", "s[52:53]", "s[54:55]", "s[56:57]", "s[58:59]")
-	MIFSK_ASM_FMA4("v113", "s[60:61]", "s[62:63]", "s[64:65]", "s[66:67]")
-	"s_add_u32 s34, s34, 0x100\n\t"
-	"s_addc_u32 s35, s35, 0\n\t"
-	"v_add_u32_e32 v119, 32, v119\n\t"
-	"s_sub_u32 s33, s33, 2\n\t"
-	"s_waitcnt lgkmcnt(0)\n\t"
-	"s_cmp_eq_u32 s33, 0\n\t"
-	"s_cbranch_scc1 2f\n\t"
-	"s_load_dwordx16 s[36:51], s[34:35], 0x0\n\t"
-	"s_load_dwordx16 s[52:67], s[34:35], 0x40\n\t"
-	"ds_read_b128 v[110:113], v119\n\t"
-	"2:\n\t"
-	MIFSK_ASM_FMA4("v114", "s[68:69]", "s[70:71]", "s[72:73]", "s[74:75]")
-	MIFSK_ASM_FMA4("v115", "s[76:77]", "s[78:79]", "s[80:81]", "s[82:83]")
-	MIFSK_ASM_FMA4("v116", "s[84:85]", "s[86:87]", "s[88:89]", "s[90:91]")
-	MIFSK_ASM_FMA4("v117", "s[92:93]", "s[94:95]", "s[96:97]", "s[98:99]")
-	"s_cmp_lg_u32 s33, 0\n\t"
-	"s_cbranch_scc1 1b\n\t"
-	"s_branch 4f\n\t"
-	"3:\n\t"
-	MIFSK_ASM_FMA4("v110", "s[36:37]", "s[38:39]", "s[40:41]", "s[42:43]")
-	MIFSK_ASM_FMA4("v111", "s[44:45]", "s[46:47]", "s[48:49]", "s[50:51]")
-	MIFSK_ASM_FMA4("v112", "s[52:53]", "s[54:55]", "s[56:57]", "s[58:59]")
-	MIFSK_ASM_FMA4("v113", "s[60:61]", "s[62:63]", "s[64:65]", "s[66:67]")
-	"4:\n\t"
-	: [mr] "+v"(mr), [mi] "+v"(mi), [sr] "+v"(sr), [si] "+v"(si)
-	: [tlo] "s"(tw_lo), [thi] "s"(tw_hi), [nh] "s"(nhalf), [addr] "v"(addr)
-	: "memory", "scc",
-	  "s33", "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45",
-	  "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58",
-	  "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71",
-	  "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84",
-	  "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97",
-	  "s98", "s99",
-	  "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v119", "v120", "v121");
-}
-
 __device__ __forceinline__ void twiddle_fetch_ro( const double *t, tw8 &a, tw8 &b, tw8 &c, tw8 &d )
 {
     // no "memory" clobber: that would make hipcc drain vmcnt, i.e. wait for the
@@ -906,61 +762,6 @@ __device__ __forceinline__ void corr_lds_fixed_halves( const TwGroup (&tg)[3], c
     if ( H + 4 < NQ ) MIFSK_QUADH(H + 4, ys[4 < H ? 4 : 0])
     if ( H + 5 < NQ ) MIFSK_QUADH(H + 5, ys[5 < H ? 5 : 0])
 #undef MIFSK_QUADH
-}
-
-// Two windows per lane, interleaved: a dependent f64 FMA can issue only every
-// ~28 cycles, so the four accumulators of one window keep a lone wave at 7
-// cycles per FMA (tools/ubench/dpp_fmac.hip); eight independent chains reach the
-// pipe's 4.  Both windows consume entry n at the same step, so one broadcast
-// register serves both.  Per window the operations and their order are those of
-// corr_lds_fixed.
-template <int J>
-__device__ __forceinline__ void fma4_bcast2( double (&a)[4], double (&b)[4], const TwGroup &G, float xa, float xb )
-{
-    const double da = (double)xa, db = (double)xb;
-    fmac_bcast<J>(a[0], G.w[0], da);
-    fmac_bcast<J>(b[0], G.w[0], db);
-    fmac_bcast<J>(a[1], G.w[1], da);
-    fmac_bcast<J>(b[1], G.w[1], db);
-    fmac_bcast<J>(a[2], G.w[2], da);
-    fmac_bcast<J>(b[2], G.w[2], db);
-    fmac_bcast<J>(a[3], G.w[3], da);
-    fmac_bcast<J>(b[3], G.w[3], db);
-}
-
-template <int J0>
-__device__ __forceinline__ void quad_bcast2( double (&a)[4], double (&b)[4], const TwGroup &G,
-	const float4 &sa, const float4 &sb )
-{
-    fma4_bcast2<J0>(a, b, G, sa.x, sb.x);
-    fma4_bcast2<J0 + 1>(a, b, G, sa.y, sb.y);
-    fma4_bcast2<J0 + 2>(a, b, G, sa.z, sb.z);
-    fma4_bcast2<J0 + 3>(a, b, G, sa.w, sb.w);
-}
-
-template <int NQ>
-__device__ __forceinline__ void corr_lds_fixed2( const TwGroup (&tg)[3], const float *pa, const float *pb,
-	double (&a)[4], double (&b)[4] )
-{
-    static_assert(NQ >= 1 && NQ <= 12, "three resident groups");
-    float4 xa[NQ], xb[NQ];
-#pragma unroll
-    for ( int q = 0; q < NQ; q++ ) {
-	xa[q] = *reinterpret_cast<const float4 *>(pa + 4 * q);
-	xb[q] = *reinterpret_cast<const float4 *>(pb + 4 * q);
-    }
-    dpp_settle();
-#define MIFSK_QUAD2(Q)									\
-    if ( (Q) < NQ ) {									\
-	constexpr int qq = (Q) < NQ ? (Q) : 0;						\
-	if ( (Q) % 4 == 0 ) quad_bcast2<0>(a, b, tg[(Q) / 4], xa[qq], xb[qq]);		\
-	if ( (Q) % 4 == 1 ) quad_bcast2<4>(a, b, tg[(Q) / 4], xa[qq], xb[qq]);		\
-	if ( (Q) % 4 == 2 ) quad_bcast2<8>(a, b, tg[(Q) / 4], xa[qq], xb[qq]);		\
-	if ( (Q) % 4 == 3 ) quad_bcast2<12>(a, b, tg[(Q) / 4], xa[qq], xb[qq]);		\
-    }
-    MIFSK_QUAD2(0) MIFSK_QUAD2(1) MIFSK_QUAD2(2) MIFSK_QUAD2(3) MIFSK_QUAD2(4) MIFSK_QUAD2(5)
-    MIFSK_QUAD2(6) MIFSK_QUAD2(7) MIFSK_QUAD2(8) MIFSK_QUAD2(9) MIFSK_QUAD2(10) MIFSK_QUAD2(11)
-#undef MIFSK_QUAD2
 }
 
 // Window of nq * 4 samples in LDS at a 16-byte aligned address, any length: one

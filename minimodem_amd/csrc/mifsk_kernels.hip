@@ -1269,15 +1269,10 @@ template <bool USE_SLAB, int NQ>
 __global__ __launch_bounds__(BLOCK, 4)
 void demod_kernel( const DevCfg *__restrict__ cfgp, const double *__restrict__ tw,
 	mifsk_demod_io io, uint32_t slab_cap, uint32_t lat_frames, uint32_t lat_rounds,
-	uint32_t region_floats, uint32_t region_cap, uint32_t lat_mode,
-	const double *const *__restrict__ tw_v, const uint32_t *__restrict__ start_v )
+	uint32_t region_floats, uint32_t region_cap, uint32_t lat_mode )
 {
     StreamLds *lds = reinterpret_cast<StreamLds *>(mifsk_smem);
-    // --auto-carrier: this stream's own tone pair (table) and the cursor the
-    // search starts at, both found by carrier_scan_kernel (mifsk_carrier.hip)
-    if ( tw_v )
-	tw = tw_v[blockIdx.x];
-    const uint32_t base0 = start_v ? start_v[blockIdx.x] : 0u;
+    const uint32_t base0 = 0u;
     // the configuration lives in device memory (uniform -> scalar loads); it is
     // NOT a by-value kernel argument so that the worker body below can be a real
     // function with its own register allocation
@@ -1361,8 +1356,7 @@ static constexpr size_t kLdsHeader = offsetof(StreamLds, slab);
 static constexpr size_t kLdsPerCu = 160 * 1024;
 
 int launch_demod_batch( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_tw,
-	const mifsk_demod_io &io, void *stream,
-	const double *const *d_tw_v, const uint32_t *d_start_v )
+	const mifsk_demod_io &io, void *stream )
 {
     if ( io.nstreams <= 0 )
 	return 0;
@@ -1461,8 +1455,7 @@ int launch_demod_batch( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_
     hipStream_t st = (hipStream_t)stream;
     if ( use_slab ) {
 	const size_t lds_bytes = kLdsHeader + slab_floats * 4;
-	// (per-stream tone tables, --auto-carrier, keep the scalar-cache correlator)
-	const bool bell202 = lat_mode == LAT_LINEAR && B == 40u && !d_tw_v;
+	const bool bell202 = lat_mode == LAT_LINEAR && B == 40u;
 	hipError_t e = hipFuncSetAttribute(
 		bell202 ? reinterpret_cast<const void *>(&demod_kernel<true, 10>)
 			: reinterpret_cast<const void *>(&demod_kernel<true, 0>),
@@ -1472,15 +1465,14 @@ int launch_demod_batch( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_
 	if ( bell202 )
 	    hipLaunchKernelGGL((demod_kernel<true, 10>), dim3((unsigned)io.nstreams), dim3(BLOCK),
 			       lds_bytes, st, d_cfg, d_tw, io, slab_cap, lat_frames, lat_rounds,
-			       (uint32_t)region_floats, region_cap, lat_mode, d_tw_v, d_start_v);
+			       (uint32_t)region_floats, region_cap, lat_mode);
 	else
 	    hipLaunchKernelGGL((demod_kernel<true, 0>), dim3((unsigned)io.nstreams), dim3(BLOCK),
 			       lds_bytes, st, d_cfg, d_tw, io, slab_cap, lat_frames, lat_rounds,
-			       (uint32_t)region_floats, region_cap, lat_mode, d_tw_v, d_start_v);
+			       (uint32_t)region_floats, region_cap, lat_mode);
     } else {
 	hipLaunchKernelGGL((demod_kernel<false, 0>), dim3((unsigned)io.nstreams), dim3(BLOCK),
-			   kLdsHeader + 16, st, d_cfg, d_tw, io, 0u, 0u, 1u, 0u, 0u, (uint32_t)LAT_NONE,
-			   d_tw_v, d_start_v);
+			   kLdsHeader + 16, st, d_cfg, d_tw, io, 0u, 0u, 1u, 0u, 0u, (uint32_t)LAT_NONE);
     }
     return hip_rc(hipGetLastError());
 }

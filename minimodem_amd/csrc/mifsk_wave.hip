@@ -153,6 +153,7 @@ struct Wave {
     // counters
     uint32_t		n_blocks, n_scans, n_positions, n_hits, n_stages;
     uint32_t		cyc_block, cyc_scan, cyc_stage, cyc_corr, cyc_conf;
+    uint32_t		cyc_s_stage, cyc_s_corr, cyc_s_conf;
 
     __device__ __forceinline__ Wave( const DevCfg &c, const WaveGeom &gg, const double *t,
 	    const float *xs, uint32_t n, float2 *m, float *s, float *r, uint32_t safe )
@@ -160,7 +161,8 @@ struct Wave {
 	  safe_limit(safe), slab_lo(0), slab_hi(0), l_conf(0.0f), l_ampl(0.0f), l_bits(0),
 	  lat_n(0), lat_anchor(0), spec(gg.lat_fmin), run(0), cold(0), pause(0),
 	  pref_lo(0xFFFFFFFFu), n_blocks(0), n_scans(0), n_positions(0), n_hits(0), n_stages(0),
-	  cyc_block(0), cyc_scan(0), cyc_stage(0), cyc_corr(0), cyc_conf(0)
+	  cyc_block(0), cyc_scan(0), cyc_stage(0), cyc_corr(0), cyc_conf(0),
+	  cyc_s_stage(0), cyc_s_corr(0), cyc_s_conf(0)
     {
 #pragma unroll
 	for ( int i = 0; i < SV; i++ )
@@ -271,35 +273,18 @@ struct Wave {
 	const uint32_t t_mid = MIFSK_WCLOCK();
 	cyc_stage += t_mid - t_in;
 	const uint32_t nq = B >> 2;				// (linear: B % 4 == 0; == NQ when NQ > 0)
-	if constexpr ( NQ > 0 ) {
-	    // the instantiation for this bit length: table resident, two windows
-	    // per lane (w and w + 64) for eight independent FMA chains
-	    for ( uint32_t s0 = 0; s0 < nw; s0 += 128u ) {
-		const uint32_t wa = w0 + s0 + lane, wb = wa + 64u;
-		const bool act_a = s0 + lane < nw, act_b = s0 + 64u + lane < nw;
-		// idle lanes shadow the round's first window
-		const uint32_t rel_a = A + win_rel(act_a ? wa : w0) - lo;
-		const uint32_t rel_b = A + win_rel(act_b ? wb : w0) - lo;
-		double acc_a[4] = { 0.0, 0.0, 0.0, 0.0 }, acc_b[4] = { 0.0, 0.0, 0.0, 0.0 };
-		corr_lds_fixed2<NQ>(tgr, slab + rel_a, slab + rel_b, acc_a, acc_b);
-		if ( act_a )
-		    mags[wa] = make_float2(band_mag(acc_a[0], acc_a[1], cfg.magscalar),
-					   band_mag(acc_a[2], acc_a[3], cfg.magscalar));
-		if ( act_b )
-		    mags[wb] = make_float2(band_mag(acc_b[0], acc_b[1], cfg.magscalar),
-					   band_mag(acc_b[2], acc_b[3], cfg.magscalar));
-	    }
-	} else {
-	    for ( uint32_t s0 = 0; s0 < nw; s0 += 64u ) {
-		const uint32_t w = w0 + s0 + lane;
-		const bool active = s0 + lane < nw;
-		const uint32_t rel = A + win_rel(active ? w : w0) - lo;	// idle lanes shadow the first window
-		double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
+	for ( uint32_t s0 = 0; s0 < nw; s0 += 64u ) {
+	    const uint32_t w = w0 + s0 + lane;
+	    const bool active = s0 + lane < nw;
+	    const uint32_t rel = A + win_rel(active ? w : w0) - lo;	// idle lanes shadow the first window
+	    double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
+	    if constexpr ( NQ > 0 )
+		corr_lds_fixed<NQ>(tgr, slab + rel, acc);	// the instantiation for this bit length
+	    else
 		corr_lds_stream(tw, slab + rel, nq, lane, acc);
-		if ( active )
-		    mags[w] = make_float2(band_mag(acc[0], acc[1], cfg.magscalar),
-					  band_mag(acc[2], acc[3], cfg.magscalar));
-	    }
+	    if ( active )
+		mags[w] = make_float2(band_mag(acc[0], acc[1], cfg.magscalar),
+				      band_mag(acc[2], acc[3], cfg.magscalar));
 	}
 	wave_lds_sync();			// the slab is rewritten by the next round
 	cyc_corr += MIFSK_WCLOCK() - t_mid;
@@ -508,6 +493,7 @@ struct Wave {
 	    const uint32_t tlo = has_down ? zz.at(ld) : zz.at(c0);
 	    const uint32_t lo = base + tlo, hi = base + thi + cfg.last_reach;
 	    bool use_slab = g.slab_cap != 0u && hi - lo + 8u <= g.slab_cap;
+	    const uint32_t ts0 = MIFSK_WCLOCK();
 	    if ( use_slab && ( ring || lo < slab_lo || hi > slab_hi ) ) {
 		// Without a carrier the searches that follow advance through the
 		// stream and reuse what is staged now: fill the slab.  With the
@@ -522,13 +508,18 @@ struct Wave {
 		wave_lds_sync();
 		n_stages++;
 	    }
+	    const uint32_t ts1 = MIFSK_WCLOCK();
 	    scan_correlate(base, zz, c0, Q, use_slab);
 	    wave_lds_sync();
+	    const uint32_t ts2 = MIFSK_WCLOCK();
 	    FrameOut f;
 	    f.conf = 0.0f; f.ampl = 0.0f; f.bits = 0;
 	    if ( lane < Q )
 		f = frame_confidence_any(&mags[lane * nb], cfg.req_mask[kind], cfg.req_val[kind], nb);
 	    wave_lds_sync();			// mags[] is free again
+	    cyc_s_stage += ts1 - ts0;
+	    cyc_s_corr += ts2 - ts1;
+	    cyc_s_conf += MIFSK_WCLOCK() - ts2;
 	    n_scans++;
 	    n_positions += Q;
 	    // fsk.c:492-501 over the chunk, in scan order on lane values
@@ -574,7 +565,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char mifsk_wave_smem[];
 // (the wide-staging instantiation runs where a wave has >= 10 KiB of LDS to
 // itself, i.e. at most 2-3 waves per SIMD: it may use 256 VGPRs)
 template <int SV, int NQ>
-__global__ __launch_bounds__(64, SV >= 20 ? 1 : SV >= 10 ? 2 : 4)
+__global__ __launch_bounds__(64, SV >= 10 ? 2 : 4)
 void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restrict__ tw_default,
 	mifsk_demod_io io, WaveGeom g, WaveAuto au )
 {
@@ -1074,6 +1065,9 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 	    c[13] = ctx.cyc_stage;
 	    c[14] = ctx.cyc_corr;
 	    c[16] = cyc_general;
+	    c[17] = ctx.cyc_s_stage;
+	    c[18] = ctx.cyc_s_corr;
+	    c[19] = ctx.cyc_s_conf;
 	    c[22] = n_detect;
 	}
     }
@@ -1215,14 +1209,9 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
     if ( want > 16u ) want = 16u;
     Plan plan;
     bool ok = false;
-    // bit lengths with a resident-table instantiation at the widest staging
-    const bool wide_ok = cfg.lat_linear && ( cfg.bit_nsamples == 40u || cfg.bit_nsamples == 20u );
     for ( uint32_t wpc = want; wpc >= 4u && !ok; wpc -= ( wpc > 8u ? 4u : ( wpc > 4u ? 2u : 1u ) ) ) {
 	const size_t budget = ( kLdsPerCu / wpc ) & ~(size_t)255;
-	// widest staging first (two windows per lane want 128-window rounds)
-	ok = wide_ok && plan_for(cfg, ha, 20, budget, plan) && plan.g.slab_cap != 0u;
-	if ( !ok )
-	    ok = plan_for(cfg, ha, 10, budget, plan) && plan.g.slab_cap != 0u;
+	ok = plan_for(cfg, ha, 10, budget, plan) && plan.g.slab_cap != 0u;
 	if ( !ok )
 	    ok = plan_for(cfg, ha, 4, budget, plan) && plan.g.slab_cap != 0u;
 	if ( wpc == 4u )
@@ -1265,12 +1254,9 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
 	hipLaunchKernelGGL((demod_wave_kernel<SV_, NQ_>), dim3((unsigned)io.nstreams), dim3(64),		\
 			   plan.lds_bytes, st, d_cfg, d_tw, io, g, au);						\
     } while (0)
-    if ( plan.sv == 20 ) {
-	if ( nq == 10u )     MIFSK_WAVE_LAUNCH(20, 10);		// 1200 baud at 48 kHz
-	else                 MIFSK_WAVE_LAUNCH(20, 5);		// 2400 baud; 1200 baud at 24 kHz
-    } else if ( plan.sv == 10 ) {
-	if ( nq == 10u )     MIFSK_WAVE_LAUNCH(10, 10);
-	else if ( nq == 5u ) MIFSK_WAVE_LAUNCH(10, 5);
+    if ( plan.sv == 10 ) {
+	if ( nq == 10u )     MIFSK_WAVE_LAUNCH(10, 10);		// 1200 baud at 48 kHz
+	else if ( nq == 5u ) MIFSK_WAVE_LAUNCH(10, 5);		// 2400 baud; 1200 baud at 24 kHz
 	else                 MIFSK_WAVE_LAUNCH(10, 0);
     } else {
 	if ( nq == 1u )      MIFSK_WAVE_LAUNCH(4, 1);		// 12000 baud
