@@ -46,6 +46,7 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 
 #include "mifsk_device.h"
@@ -1207,11 +1208,21 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
     uint32_t want = ( (uint32_t)io.nstreams + (uint32_t)ncu - 1u ) / (uint32_t)ncu;
     if ( want < 4u ) want = 4u;
     if ( want > 16u ) want = 16u;
+    int force_sv = 0;
+    if ( const char *e = std::getenv("MIFSK_WAVES_PER_CU") )	// experiments only
+	want = (uint32_t)std::atoi(e) < 1u ? 1u : (uint32_t)std::atoi(e);
+    if ( const char *e = std::getenv("MIFSK_SV") )
+	force_sv = std::atoi(e);
     Plan plan;
     bool ok = false;
     for ( uint32_t wpc = want; wpc >= 4u && !ok; wpc -= ( wpc > 8u ? 4u : ( wpc > 4u ? 2u : 1u ) ) ) {
 	const size_t budget = ( kLdsPerCu / wpc ) & ~(size_t)255;
-	ok = plan_for(cfg, ha, 10, budget, plan) && plan.g.slab_cap != 0u;
+	// The wide-staging instantiation is compiled for two waves per SIMD (256
+	// VGPRs): worth it where rounds are staged through LDS (linear LATTICE) or
+	// where no more than 8 waves per CU are wanted anyway
+	const bool wide = force_sv ? force_sv == 10 : ( wpc <= 8u || cfg.lat_linear );
+	ok = wide && plan_for(cfg, ha, 10, budget, plan) && plan.g.slab_cap != 0u
+		  && ( plan.g.lat_mode == LAT_LINEAR || wpc <= 8u || force_sv == 10 );
 	if ( !ok )
 	    ok = plan_for(cfg, ha, 4, budget, plan) && plan.g.slab_cap != 0u;
 	if ( wpc == 4u )
@@ -1225,6 +1236,9 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
 	if ( !ok )
 	    return -12;
     }
+    if ( const char *e = std::getenv("MIFSK_LDS_PAD") )	// experiments only: limit occupancy
+	if ( (size_t)std::atoi(e) > plan.lds_bytes )
+	    plan.lds_bytes = (size_t)std::atoi(e);
     WaveGeom &g = plan.g;
     g.bufsize = ha.samplebuf_size;
     g.ring_exact = ha.ring_exact ? 1u : 0u;
