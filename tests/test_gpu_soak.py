@@ -13,9 +13,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-def test_soak_seed_7():
+@pytest.mark.parametrize("variant", [[], ["--ring"], ["--engine", "workgroup"]],
+                         ids=["wave-flat", "wave-ring", "workgroup-flat"])
+def test_soak_seed_7(variant):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak.py"), "--seed", "7",
-                        "--streams", "24"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                        "--streams", "24"] + variant, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        timeout=600)
     out = r.stdout.decode()
     assert r.returncode == 0, out[-2000:]

@@ -54,12 +54,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--streams", type=int, default=96)
+    ap.add_argument("--engine", default="wave", choices=["wave", "workgroup"])
+    ap.add_argument("--ring", action="store_true", help="RING addressing (wave engine), oracle ring_mode")
     args = ap.parse_args()
     import torch
     ctx = M.Context(0)
     rng = np.random.default_rng(args.seed)
     total_frames = bad = 0
     for mode, kw in MODES:
+        if args.engine == "workgroup" and kw.get("auto_carrier_threshold"):
+            continue                    # --auto-carrier runs on the wavefront engine only
         cfg = M.rx_config(mode, **kw)
         ocfg = O.oracle_config(mode, **kw)
         streams = [make_stream(rng, cfg, mode) for _ in range(args.streams)]
@@ -73,10 +77,11 @@ def main():
         t = time.time()
         res = M.results_to_host(M.demod_batch(ctx, cfg, torch.from_numpy(host).cuda(),
                                               nsamples=torch.from_numpy(lens).cuda(),
-                                              want=("bytes", "frames", "episodes"), episodes_cap=64))
+                                              want=("bytes", "frames", "episodes"), episodes_cap=64,
+                                              engine=args.engine, ring_exact=args.ring))
         nf = 0
         for i, s in enumerate(streams):
-            ref = O.oracle_rx_stream(ocfg, s, ring_mode=False)
+            ref = O.oracle_rx_stream(ocfg, s, ring_mode=args.ring)
             n, ne = int(res["nframes"][i]), int(res["nepisodes"][i])
             ok = (n == len(ref["frames"]) and ne == len(ref["episodes"])
                   and res["frames"][i, :n].tobytes() == ref["frames"].tobytes()
@@ -89,7 +94,8 @@ def main():
             nf += n
         total_frames += nf
         print("%-6s %-40s %4d streams %7d frames  %.1f s" % (mode, kw, len(streams), nf, time.time() - t))
-    print("seed %d: %d frames compared, %d mismatching streams" % (args.seed, total_frames, bad))
+    print("seed %d (%s engine, %s addressing): %d frames compared, %d mismatching streams"
+          % (args.seed, args.engine, "ring" if args.ring else "flat", total_frames, bad))
     sys.exit(1 if bad else 0)
 
 
