@@ -70,9 +70,10 @@ fsk_plan_destroy( fsk_plan *fskp );
 
 /*
  * Search `samples` for the best frame.  `samples` is a caller-owned HOST
- * buffer (mono f32) that must hold at least
- *     try_max_nsamples + frame_nsamples (+1 bit of slack, as in the reference)
- * readable floats; it is never written.  `expect_bits_string` is a borrowed
+ * buffer (mono f32); it is never written.  Exactly the floats the reference
+ * can touch are read: up to the highest candidate it may try,
+ * try_first + k * try_step < try_max, plus the last bit window
+ * (src/fsk.c:204-206,477-484).  `expect_bits_string` is a borrowed
  * NUL-terminated string over {'0','1','d'} of at most 64 characters.
  * Returns the best confidence (0.0 when no candidate matched) and ALWAYS
  * writes *bits_outp, *ampl_outp and *frame_start_outp (zeros when nothing

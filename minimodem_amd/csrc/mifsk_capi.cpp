@@ -692,7 +692,13 @@ extern "C" float fsk_find_frame( fsk_plan *p, float *samples, unsigned int frame
     c.b_mark = p->b_mark;
     c.b_space = p->b_space;
 
-    const size_t reach = (size_t)try_max_nsamples - 1 + c.bit_offset[n_bits - 1] + c.bit_nsamples;
+    // what the reference can touch (fsk.c:204-206,477-484): the highest candidate
+    // it may try, first + k * step < try_max, plus the last bit window -- not
+    // try_max - 1: a caller whose buffer ends at the reference's true extent
+    // must not be over-read
+    const unsigned up_steps = ( try_max_nsamples - try_first_sample - 1u ) / try_step_nsamples;
+    const size_t t_last = (size_t)try_first_sample + (size_t)up_steps * try_step_nsamples;
+    const size_t reach = t_last + c.bit_offset[n_bits - 1] + c.bit_nsamples;
     if ( hipSetDevice(lp->ctx->device) != hipSuccess || legacy_reserve(lp, reach) )
 	return 0.0f;
     mifsk_search pr;
