@@ -580,7 +580,9 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 {
     const uint32_t s = blockIdx.x;
     const float *x = io.d_samples + (size_t)s * io.stream_stride;
-    const uint32_t N = io.d_nsamples ? io.d_nsamples[s] : io.nsamples;
+    uint32_t N = io.d_nsamples ? io.d_nsamples[s] : io.nsamples;
+    if ( io.nstreams > 1 && (size_t)N > io.stream_stride )
+	N = (uint32_t)io.stream_stride;		// never trust a length beyond the row
     StreamOut o;
     o.fcap = io.frames_cap;
     o.ecap = io.episodes_cap;
@@ -1286,7 +1288,9 @@ void demod_kernel( const DevCfg *__restrict__ cfgp, const double *__restrict__ t
     // without leaving the batch: the rows after it, or for the last row its own
     // length.  The linear LATTICE fetches whole rounds of 64 * STAGE_VEC float4
     // with no per-lane bounds logic and needs at least one round of room.
-    const uint32_t n_own = io.d_nsamples ? io.d_nsamples[blockIdx.x] : io.nsamples;
+    uint32_t n_own = io.d_nsamples ? io.d_nsamples[blockIdx.x] : io.nsamples;
+    if ( io.nstreams > 1 && (size_t)n_own > io.stream_stride )
+	n_own = (uint32_t)io.stream_stride;
     const uint64_t rows_after = (uint64_t)( io.nstreams - 1 - (int)blockIdx.x ) * io.stream_stride;
     const uint32_t safe_limit = rows_after == 0 ? n_own
 			      : rows_after > 0xFFFF0000ull ? 0xFFFF0000u : (uint32_t)rows_after;
