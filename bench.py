@@ -397,7 +397,7 @@ def main():
         value = total_samples * args.steps / dt
         kavg = float(np.mean(kernel_ms)) * 1e-3
         achieved = total_samples_local * 4.0 / kavg
-        engine = args.engine or ("workgroup" if (name == "1200" and nstreams < 2048) else "wave")
+        engine = args.engine or ("workgroup" if name == "1200" else "wave")	# (the library's choice)
         line = {
             "metric": "audio samples/sec demodulated (whole node), %s-baud 48 kHz f32"
                       % {"1200": "1200", "rtty": "45.45", "12000": "12000", "same": "520.83"}[name],

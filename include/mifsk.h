@@ -253,9 +253,9 @@ typedef struct mifsk_demod_io {
  * worker waves; the round-1 kernel) instead of one wavefront per stream.
  * Flat addressing only; --auto-carrier looks for the tone once per stream. */
 #define MIFSK_IO_ENGINE_WORKGROUP 2u
-/* ... or with one wavefront per stream whatever the batch looks like.  With
- * neither flag the library chooses (the workgroup engine for batches of fewer
- * streams than two wavefronts per SIMD in the modes it pipelines). */
+/* ... or with one wavefront per stream whatever the mode.  With neither flag the
+ * library chooses (the workgroup engine in the modes whose bit windows it
+ * stages through LDS and that have at least 16 samples per bit). */
 #define MIFSK_IO_ENGINE_WAVE	4u
 
 /* per-stream work counters (diagnostics; cycle counts are s_memtime ticks) */

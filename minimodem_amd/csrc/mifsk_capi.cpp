@@ -402,15 +402,17 @@ extern "C" int mifsk_demod_batch( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
     if ( io->nstreams == 0 )
 	return 0;
     // Engine.  One wavefront per stream is the general engine (every option,
-    // any stream count).  A batch with fewer streams than two waves per SIMD
-    // leaves a lone wave nothing to hide its latencies behind; where the
-    // workgroup engine has its pipelined linear LATTICE (bit length and frame
-    // step in multiples of 4 samples: Bell-202, 2400 baud, ...) it spreads each
-    // stream over four waves instead.  Identical results either way.
+    // every mode).  Where bit windows are staged through LDS and long enough
+    // that correlation, not the per-frame decisions, is the work (linear
+    // LATTICE, >= 16 samples per bit: Bell-202, 2400 baud, ...), the workgroup
+    // engine's master / worker pipeline overlaps the two and wins at every
+    // batch size measured (0.32 vs 0.52 ms at 512 streams, 0.50 vs 0.59 at
+    // 1024, 1.64 vs 2.19 at 4096); at 12000 baud (4 samples per bit) the
+    // wavefront engine is 4 x faster.  Identical results either way.
     const bool plain = !( io->flags & MIFSK_IO_RING_EXACT ) && !( cfg->auto_carrier_threshold > 0.0f );
     bool workgroup = plain && !( io->flags & MIFSK_IO_ENGINE_WAVE )
 		  && ( ( io->flags & MIFSK_IO_ENGINE_WORKGROUP )
-		       || ( d.lat_linear && (long)io->nstreams < 8L * ctx->ncu ) );
+		       || ( d.lat_linear && d.bit_nsamples >= 16u ) );
     if ( const char *e = std::getenv("MIFSK_ENGINE") )	// diagnostic override: "workgroup" / "wave"
 	if ( !( io->flags & ( MIFSK_IO_ENGINE_WORKGROUP | MIFSK_IO_ENGINE_WAVE ) ) )
 	    workgroup = plain && e[0] == 'w' && e[1] == 'o';

@@ -565,8 +565,11 @@ extern __shared__ __attribute__((aligned(16))) unsigned char mifsk_wave_smem[];
 
 // (the wide-staging instantiation runs where a wave has >= 10 KiB of LDS to
 // itself, i.e. at most 2-3 waves per SIMD: it may use 256 VGPRs)
+#ifndef MIFSK_WAVE_OCC
+#define MIFSK_WAVE_OCC 4	// waves per SIMD the narrow-staging instantiations are compiled for
+#endif
 template <int SV, int NQ>
-__global__ __launch_bounds__(64, SV >= 10 ? 2 : 4)
+__global__ __launch_bounds__(64, SV >= 10 ? 2 : MIFSK_WAVE_OCC)
 void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restrict__ tw_default,
 	mifsk_demod_io io, WaveGeom g, WaveAuto au )
 {
