@@ -464,29 +464,58 @@ __device__ __forceinline__ void replay_scan_asm( float &xt, float &xpk, float &x
 // falls below 0.75 x the running peak is an ordinary frame with one side effect,
 //     peak_confidence = 0  (:1281)   and then   peak_confidence = confidence  (:1392-1393),
 // i.e. the peak recurrence is  pk <- (c < 0.75 pk) ? c : max(pk, c)  instead of a
-// plain running maximum.  Written with DPP moves under full EXEC and selects (no
-// branch on the lane: a lane whose source lane is masked off would not be
-// written); `steps` applications settle lanes 0 .. steps.
+// plain running maximum: three more instructions per step than replay_scan_asm
+// (the threshold 0.75 * pk[l-1] and the maximum through DPP, then a select).
+// Lane 0 keeps its seed as there: the DPP instructions never write it, its
+// threshold stays -inf (so the comparison is false) and its `mx` stays the seed.
 __device__ __forceinline__ void replay_scan_soft( float &xt, float &xpk, float &xsc, float &xsa,
 	float &bt, float &bpk, float &bsc, float &bsa, float cv, float av, uint32_t K, uint32_t lane )
 {
-    const bool upper = lane > 0u;
-    for ( uint32_t step = 1; step < K; step++ ) {
-	const float pt = wave_shr1(xt), ppk = wave_shr1(xpk), psc = wave_shr1(xsc), psa = wave_shr1(xsa);
-	const float nt = ( pt + av ) / 2.0f;				// minimodem.c:1391
-	const float mx = ppk < cv ? cv : ppk;				// :1392-1393
-	const float npk = cv < ppk * 0.75f ? cv : mx;			// :1278-1281 first
-	xt = upper ? nt : xt;
-	xpk = upper ? npk : xpk;
-	xsc = upper ? psc + cv : xsc;					// :1397-1398
-	xsa = upper ? psa + av : xsa;
-    }
-    // the state BEFORE each lane's frame: the lower neighbour's "after" (lane 0 keeps the seed)
-    const float pt = wave_shr1(xt), ppk = wave_shr1(xpk), psc = wave_shr1(xsc), psa = wave_shr1(xsa);
-    bt = upper ? pt : bt;
-    bpk = upper ? ppk : bpk;
-    bsc = upper ? psc : bsc;
-    bsa = upper ? psa : bsa;
+    (void)lane;
+    float yt = xt, ypk = xpk, ysc = xsc, ysa = xsa;
+    float tmp = xt + xt;
+    float thr = -INFINITY, mx = xpk;
+    const float k075 = 0.75f;
+    const uint32_t pairs = K / 2u;		// 2 * pairs >= K - 1 steps
+#define MIFSK_SOFT_STEP(ST, SPK, SSC, SSA, DT, DPK, DSC, DSA)						\
+	"v_add_f32_dpp %[tmp], " ST ", %[av] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"		\
+	"v_mul_f32_dpp %[thr], " SPK ", %[k075] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"		\
+	"v_max_f32_dpp %[mx], " SPK ", %[cv] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"		\
+	"v_mul_f32_e32 " DT ", 0.5, %[tmp]\n\t"								\
+	"v_cmp_lt_f32_e32 vcc, %[cv], %[thr]\n\t"								\
+	"v_add_f32_dpp " DSC ", " SSC ", %[cv] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"		\
+	"v_add_f32_dpp " DSA ", " SSA ", %[av] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"		\
+	"v_cndmask_b32_e32 " DPK ", %[mx], %[cv], vcc\n\t"
+    uint32_t n = pairs;
+    // (s_nop: a VGPR written by a VALU instruction may be read through DPP only two
+    // wait states later; inside a step every DPP source was written >= 2 instructions
+    // earlier, the last-written DPK is first read three instructions into the next step)
+    asm volatile(
+	"s_nop 1\n\t"
+	"s_cmp_eq_u32 %[n], 0\n\t"
+	"s_cbranch_scc1 2f\n\t"
+	"1:\n\t"
+	MIFSK_SOFT_STEP("%[xt]", "%[xpk]", "%[xsc]", "%[xsa]", "%[yt]", "%[ypk]", "%[ysc]", "%[ysa]")
+	"s_sub_u32 %[n], %[n], 1\n\t"
+	"s_nop 0\n\t"
+	MIFSK_SOFT_STEP("%[yt]", "%[ypk]", "%[ysc]", "%[ysa]", "%[xt]", "%[xpk]", "%[xsc]", "%[xsa]")
+	"s_cmp_lg_u32 %[n], 0\n\t"
+	"s_nop 0\n\t"
+	"s_cbranch_scc1 1b\n\t"
+	"s_nop 1\n\t"
+	"2:\n\t"
+	"v_mov_b32_dpp %[bt], %[xt] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+	"v_mov_b32_dpp %[bpk], %[xpk] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+	"v_mov_b32_dpp %[bsc], %[xsc] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+	"v_mov_b32_dpp %[bsa], %[xsa] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+	"s_nop 1\n\t"
+	: [bt] "+v"(bt), [bpk] "+v"(bpk), [bsc] "+v"(bsc), [bsa] "+v"(bsa),
+	  [xt] "+v"(xt), [xpk] "+v"(xpk), [xsc] "+v"(xsc), [xsa] "+v"(xsa),
+	  [yt] "+v"(yt), [ypk] "+v"(ypk), [ysc] "+v"(ysc), [ysa] "+v"(ysa),
+	  [tmp] "+v"(tmp), [thr] "+v"(thr), [mx] "+v"(mx), [n] "+s"(n)
+	: [cv] "v"(cv), [av] "v"(av), [k075] "v"(k075)
+	: "scc", "vcc");
+#undef MIFSK_SOFT_STEP
 }
 
 __device__ __forceinline__ float lane_bcast( float v, uint32_t src )
