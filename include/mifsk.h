@@ -383,9 +383,9 @@ long mifsk_tx_synthesize( const mifsk_rx_config *cfg, const uint8_t *words, size
  * d_words[s][0 .. nwords[s]) (uniform `nwords` when d_nwords is NULL) behind
  * leading_silence[s] zero samples, written to d_out[s][..out_stride) with the rest
  * of the row zeroed; d_nsamples_out[s] receives its length (which may exceed
- * out_stride: the row is then cut).  Table-lookup mode only (-ENOTSUP for
- * sin_table_len == 0, i.e. --lut=0, which needs the host's sinf).  Bit-identical
- * to mifsk_tx_synthesize.  Asynchronous on `stream`. */
+ * out_stride: the row is then cut).  sin_table_len == 0 is --lut=0 (a sinf per
+ * sample: glibc's algorithm restated on the device, csrc/mifsk_sinf.h).
+ * Bit-identical to mifsk_tx_synthesize.  Asynchronous on `stream`. */
 int mifsk_tx_synthesize_batch( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
 	const uint8_t *d_words, size_t words_stride, const uint32_t *d_nwords, uint32_t nwords,
 	int nstreams, unsigned sin_table_len, float amplitude,

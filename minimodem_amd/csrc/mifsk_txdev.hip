@@ -3,9 +3,10 @@
 // (src/minimodem.c:81-250: leader, sync preamble, start / data / stop tones,
 // trailer) and the phase-continuous table-lookup tone generator
 // (src/simple-tone-generator.c:106-175).  Bit-identical to csrc/mifsk_tx.cpp,
-// which is pinned to the WAV files the reference writes; the sine TABLE is built
-// on the host with the host's sinf (that is what pins it), so only the default
-// table-lookup mode exists here (--lut=0 needs glibc's sinf: host path only).
+// which is pinned to the WAV files the reference writes.  The sine TABLE is built
+// on the host with the host's sinf; --lut=0 (a sinf per sample,
+// simple-tone-generator.c:134,155) uses the restatement of glibc's sinf in
+// mifsk_sinf.h, pinned to the C library over every non-negative float.
 // gfx950 only.
 #include <hip/hip_runtime.h>
 
@@ -16,6 +17,7 @@
 
 #include "mifsk.h"
 #include "mifsk_device.h"
+#include "mifsk_sinf.h"
 
 namespace mifsk {
 
@@ -27,7 +29,9 @@ struct TxArgs {
     const uint32_t	*d_lead;	uint32_t lead;
     const float		*tab_f;		// [table_len] mag * sinf
     const short		*tab_s;		// [table_len] what an S16 file holds
-    uint32_t		table_len;
+    uint32_t		table_len;	// 0: --lut=0, sinf per sample
+    float		mag;		// tone_mag
+    float		mag_s;		// (float)(unsigned short) 32767 * tone_mag, clamped (:150-154)
     int			as_s16;
     float		*d_out;		size_t out_stride;
     uint32_t		*d_nsamples;
@@ -146,9 +150,16 @@ void tx_synth_kernel( TxArgs a )
 	    const uint32_t i = j - s_off[lo];
 	    const float wave_nsamples = (float)a.sample_rate / s_freq[lo];
 	    const float turns = (float)i / wave_nsamples + s_phase[lo];	// :118
-	    int ti = (int)( (float)a.table_len * turns + 0.5f );		// :120-121
-	    ti %= (int)a.table_len;
-	    const float v = a.as_s16 ? (float)a.tab_s[ti] / 32768.0f : a.tab_f[ti];
+	    float v;
+	    if ( a.table_len ) {
+		int ti = (int)( (float)a.table_len * turns + 0.5f );		// :120-121
+		ti %= (int)a.table_len;
+		v = a.as_s16 ? (float)a.tab_s[ti] / 32768.0f : a.tab_f[ti];
+	    } else {
+		const float rad = (float)M_PI * 2 * turns;			// :116,134,155
+		const float sn = mifsk_glibc_sinf(rad);
+		v = a.as_s16 ? (float)(short)lroundf(a.mag_s * sn) / 32768.0f : a.mag * sn;
+	    }
 	    if ( pos + j < cap )
 		out[pos + j] = v;
 	}
@@ -214,16 +225,28 @@ extern "C" int mifsk_tx_synthesize_batch( mifsk_ctx *ctx, const mifsk_rx_config 
     if ( !ctx || !cfg || !d_out || nstreams < 0 || !( amplitude > 0.0f ) || cfg->n_data_bits > 8
 	    || ( !d_words && ( d_nwords || nwords ) ) )
 	return -EINVAL;
-    if ( sin_table_len == 0 )
-	return -ENOTSUP;		// --lut=0 is sinf per sample: host generator only
     if ( nstreams == 0 )
 	return 0;
     if ( hipSetDevice(mifsk::ctx_device(ctx)) != hipSuccess )
 	return -EIO;
     mifsk::TxArgs a;
-    int rc = get_table(sin_table_len, amplitude, &a.tab_f, &a.tab_s);
-    if ( rc )
-	return rc;
+    a.tab_f = nullptr;
+    a.tab_s = nullptr;
+    if ( sin_table_len ) {
+	int rc = get_table(sin_table_len, amplitude, &a.tab_f, &a.tab_s);
+	if ( rc )
+	    return rc;
+    }
+    a.mag = amplitude;
+    {
+	// simple-tone-generator.c:150-154
+	unsigned short mag_s = (unsigned short)( 32767.0f * amplitude + 0.5f );
+	if ( amplitude > 1.0f )
+	    mag_s = 32767;
+	if ( mag_s < 1 )
+	    mag_s = 1;
+	a.mag_s = (float)mag_s;
+    }
     a.d_words = d_words;	a.words_stride = words_stride;
     a.d_nwords = d_nwords;	a.nwords = nwords;
     a.d_lead = d_leading_silence;	a.lead = leading_silence;

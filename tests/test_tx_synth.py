@@ -23,6 +23,14 @@ TX_OPTS = {   # golden name -> synthesize() options
     "t30_ampl_0p3": dict(s16=True, amplitude=0.30),
     "t60_7bit": dict(s16=True),
     "t80_same": dict(s16=True),
+    "t09_1200_lut16_float": dict(lut=16),
+    "t11_perfect_nolut": dict(s16=True, lut=0),
+    "t12_perfect_lut16": dict(s16=True, lut=16),
+    "t15_perfect_float": dict(),
+    "t30_ampl_3p50": dict(s16=True, amplitude=3.5),
+    "t30_ampl_0p01": dict(s16=True, amplitude=0.01),
+    "t31_ampl_float_3p50": dict(amplitude=3.5),
+    "t31_ampl_float_0p01": dict(amplitude=0.01),
 }
 
 
