@@ -397,7 +397,7 @@ def main():
         value = total_samples * args.steps / dt
         kavg = float(np.mean(kernel_ms)) * 1e-3
         achieved = total_samples_local * 4.0 / kavg
-        engine = args.engine or ("workgroup" if name == "1200" else "wave")	# (the library's choice)
+        launch = M.demod_plan(ctx, cfg, nstreams, engine=args.engine)	# what the library launches
         line = {
             "metric": "audio samples/sec demodulated (whole node), %s-baud 48 kHz f32"
                       % {"1200": "1200", "rtty": "45.45", "12000": "12000", "same": "520.83"}[name],
@@ -414,7 +414,7 @@ def main():
                                     "rank 0 over RCCL") if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": hbm_traffic(name),
-                         "kernel": "mifsk::demod_kernel" if engine == "workgroup" else "mifsk::demod_wave_kernel",
+                         "kernel": launch["kernel"], "launch": launch,
                          "kernel_ms_avg": kavg * 1e3, "kernel_ms_min": float(np.min(kernel_ms)),
                          "algorithmic_bytes_per_launch": total_samples_local * 4.0},
             "payload_roundtrip_ok_streams": "%d/%d" % (ok_streams, judged),

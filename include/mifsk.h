@@ -277,6 +277,24 @@ typedef struct mifsk_demod_io {
 int mifsk_demod_batch( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
 	const mifsk_demod_io *io, void *stream );
 
+/* What mifsk_demod_batch would launch for `cfg`, a batch of `nstreams` streams and
+ * `flags` (MIFSK_IO_*): the kernel instantiation, its launch geometry and the
+ * occupancy its LDS allows -- what rocprofv3 does not report for dynamic LDS. */
+typedef struct mifsk_launch_info {
+    char	kernel[64];
+    uint32_t	engine;			/* MIFSK_IO_ENGINE_WAVE or _WORKGROUP   */
+    uint32_t	workgroup_size;		/* threads (64: a workgroup is a wave)  */
+    uint32_t	lds_bytes_per_workgroup;/* dynamic LDS                          */
+    uint32_t	workgroups_per_cu;	/* min(160 KiB / LDS, 32 waves / size): VGPRs
+					   may lower it (4 waves per SIMD at 128) */
+    uint32_t	lattice_mode;		/* 0 none, 1 LDS-staged rounds, 2 streamed */
+    uint32_t	frames_per_block;	/* LATTICE frames scored at once, at most */
+    uint32_t	compute_units;
+} mifsk_launch_info;
+
+int mifsk_demod_plan( mifsk_ctx *ctx, const mifsk_rx_config *cfg, int nstreams,
+	unsigned flags, mifsk_launch_info *out );
+
 /* Same, for HOST pointers in `io` (all fields, d_ prefix notwithstanding):
  * copies in, runs mifsk_demod_batch, copies out, synchronises. */
 int mifsk_demod_batch_host( mifsk_ctx *ctx, const mifsk_rx_config *cfg,

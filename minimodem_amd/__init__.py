@@ -204,6 +204,22 @@ def demod_batch(ctx, cfg, samples, nsamples=None, want=("bytes", "episodes"),
     return out
 
 
+def demod_plan(ctx, cfg, nstreams, ring_exact=False, engine=None):
+    """mifsk_demod_plan: what demod_batch would launch (kernel instantiation, engine,
+    workgroup size, dynamic LDS per workgroup, workgroups per CU by LDS, LATTICE mode)."""
+    info = _lib.LaunchInfo()
+    flags = (_lib.IO_RING_EXACT if ring_exact else 0) | \
+        (_lib.IO_ENGINE_WORKGROUP if engine == "workgroup" else 0) | \
+        (_lib.IO_ENGINE_WAVE if engine == "wave" else 0)
+    rc = _lib.load().mifsk_demod_plan(ctx.handle, C.byref(cfg), int(nstreams), flags, C.byref(info))
+    if rc != 0:
+        raise RuntimeError("mifsk_demod_plan failed: %d" % rc)
+    d = {k: getattr(info, k) for k, _ in info._fields_}
+    d["kernel"] = d["kernel"].decode()
+    d["engine"] = "workgroup" if d["engine"] == _lib.IO_ENGINE_WORKGROUP else "wave"
+    return d
+
+
 def results_to_host(out):
     """Copy a demod_batch() result to numpy (synchronises)."""
     res = {}

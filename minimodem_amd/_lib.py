@@ -136,6 +136,16 @@ class DemodIO(C.Structure):
         ("reserved", C.c_uint32),
     ]
 
+class LaunchInfo(C.Structure):
+    _fields_ = [
+        ("kernel", C.c_char * 64),
+        ("engine", C.c_uint32), ("workgroup_size", C.c_uint32),
+        ("lds_bytes_per_workgroup", C.c_uint32), ("workgroups_per_cu", C.c_uint32),
+        ("lattice_mode", C.c_uint32), ("frames_per_block", C.c_uint32),
+        ("compute_units", C.c_uint32),
+    ]
+
+
 IO_RING_EXACT = 1
 IO_ENGINE_WORKGROUP = 2
 IO_ENGINE_WAVE = 4
@@ -170,7 +180,7 @@ EXPORTS = [
     "mifsk_tx_tone_init", "mifsk_tx_synthesize",
     "mifsk_databits_create", "mifsk_databits_destroy", "mifsk_databits_reset",
     "mifsk_databits_decode", "mifsk_databits_encode", "mifsk_shard_range",
-    "mifsk_demod_batch_host_multi", "mifsk_stream_text",
+    "mifsk_demod_batch_host_multi", "mifsk_demod_plan", "mifsk_stream_text",
     "mifsk_wav_parse", "mifsk_ingest_s16", "mifsk_ingest_rxnoise_f32",
     "mifsk_tx_synthesize_batch",
 ]

@@ -314,11 +314,32 @@ extern "C" int mifsk_find_frame_batch( mifsk_ctx *ctx, const mifsk_rx_config *cf
 					  nproblems, stream);
 }
 
+// Engine.  One wavefront per stream is the general engine (every option,
+// every mode).  Where bit windows are staged through LDS and long enough
+// that correlation, not the per-frame decisions, is the work (linear
+// LATTICE, >= 16 samples per bit: Bell-202, 2400 baud, ...), the workgroup
+// engine's master / worker pipeline overlaps the two and wins at every
+// batch size measured (0.32 vs 0.52 ms at 512 streams, 0.50 vs 0.59 at
+// 1024, 1.64 vs 2.19 at 4096); at 12000 baud (4 samples per bit) the
+// wavefront engine is 4 x faster.  Identical results either way.
+static bool use_workgroup_engine( const mifsk_rx_config *cfg, const DevCfg &d, unsigned flags )
+{
+    const bool plain = !( flags & MIFSK_IO_RING_EXACT ) && !( cfg->auto_carrier_threshold > 0.0f );
+    bool workgroup = plain && !( flags & MIFSK_IO_ENGINE_WAVE )
+		  && ( ( flags & MIFSK_IO_ENGINE_WORKGROUP )
+		       || ( d.lat_linear && d.bit_nsamples >= 16u ) );
+    if ( const char *e = std::getenv("MIFSK_ENGINE") )	// diagnostic override: "workgroup" / "wave"
+	if ( !( flags & ( MIFSK_IO_ENGINE_WORKGROUP | MIFSK_IO_ENGINE_WAVE ) ) )
+	    workgroup = plain && e[0] == 'w' && e[1] == 'o';
+    return workgroup;
+}
+
 // One wavefront per stream (mifsk_wave.hip): --auto-carrier and RING addressing
 // need per-call device scratch; it is allocated and freed in stream order, so
 // concurrent calls on different streams never share it.
 static int demod_batch_wave( mifsk_ctx *ctx, const mifsk_rx_config *cfg, const DevCfg &d,
-	const DevCfg *d_cfg, const double *d_tw, const mifsk_demod_io *io, void *stream )
+	const DevCfg *d_cfg, const double *d_tw, const mifsk_demod_io *io, void *stream,
+	mifsk::LaunchInfo *plan_only = nullptr )
 {
     hipStream_t st = (hipStream_t)stream;
     const size_t ns = (size_t)io->nstreams;
@@ -329,6 +350,11 @@ static int demod_batch_wave( mifsk_ctx *ctx, const mifsk_rx_config *cfg, const D
     ha.fftsize = (uint32_t)cfg->fftsize;
     ha.nbands = cfg->nbands;
     ha.tw_entries = (uint32_t)mifsk::tw_entries(cfg->bit_nsamples);
+    if ( plan_only ) {
+	ha.ring_exact = ( io->flags & MIFSK_IO_RING_EXACT ) != 0;
+	ha.autodetect = cfg->auto_carrier_threshold > 0.0f;
+	return mifsk::launch_demod_wave(d, d_cfg, d_tw, *io, ha, stream, plan_only);
+    }
     void *scratch_tw = nullptr, *scratch_ring = nullptr;
     if ( cfg->auto_carrier_threshold > 0.0f ) {
 	// default negative shift, in the reference's float arithmetic (minimodem.c:1203-1206)
@@ -401,24 +427,43 @@ extern "C" int mifsk_demod_batch( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
 	return rc;
     if ( io->nstreams == 0 )
 	return 0;
-    // Engine.  One wavefront per stream is the general engine (every option,
-    // every mode).  Where bit windows are staged through LDS and long enough
-    // that correlation, not the per-frame decisions, is the work (linear
-    // LATTICE, >= 16 samples per bit: Bell-202, 2400 baud, ...), the workgroup
-    // engine's master / worker pipeline overlaps the two and wins at every
-    // batch size measured (0.32 vs 0.52 ms at 512 streams, 0.50 vs 0.59 at
-    // 1024, 1.64 vs 2.19 at 4096); at 12000 baud (4 samples per bit) the
-    // wavefront engine is 4 x faster.  Identical results either way.
-    const bool plain = !( io->flags & MIFSK_IO_RING_EXACT ) && !( cfg->auto_carrier_threshold > 0.0f );
-    bool workgroup = plain && !( io->flags & MIFSK_IO_ENGINE_WAVE )
-		  && ( ( io->flags & MIFSK_IO_ENGINE_WORKGROUP )
-		       || ( d.lat_linear && d.bit_nsamples >= 16u ) );
-    if ( const char *e = std::getenv("MIFSK_ENGINE") )	// diagnostic override: "workgroup" / "wave"
-	if ( !( io->flags & ( MIFSK_IO_ENGINE_WORKGROUP | MIFSK_IO_ENGINE_WAVE ) ) )
-	    workgroup = plain && e[0] == 'w' && e[1] == 'o';
+    const bool workgroup = use_workgroup_engine(cfg, d, io->flags);
     if ( !workgroup )
 	return demod_batch_wave(ctx, cfg, d, d_cfg, d_tw, io, stream);
     return mifsk::launch_demod_batch(d, d_cfg, d_tw, *io, stream);
+}
+
+// what mifsk_demod_batch would launch for this configuration and batch size
+extern "C" int mifsk_demod_plan( mifsk_ctx *ctx, const mifsk_rx_config *cfg, int nstreams,
+	unsigned flags, mifsk_launch_info *out )
+{
+    if ( !ctx || !out || check_cfg(cfg) || nstreams < 0 )
+	return -EINVAL;
+    DevCfg d;
+    mifsk::fill_devcfg(d, *cfg);
+    mifsk_demod_io io;
+    std::memset(&io, 0, sizeof(io));
+    io.nstreams = nstreams;
+    io.flags = flags;
+    mifsk::LaunchInfo li;
+    std::memset(&li, 0, sizeof(li));
+    const bool workgroup = use_workgroup_engine(cfg, d, flags);
+    int rc = workgroup ? mifsk::launch_demod_batch(d, nullptr, nullptr, io, nullptr, &li)
+		       : demod_batch_wave(ctx, cfg, d, nullptr, nullptr, &io, nullptr, &li);
+    if ( rc )
+	return rc;
+    std::memset(out, 0, sizeof(*out));
+    std::snprintf(out->kernel, sizeof(out->kernel), "%s", li.kernel ? li.kernel : "");
+    out->engine = workgroup ? MIFSK_IO_ENGINE_WORKGROUP : MIFSK_IO_ENGINE_WAVE;
+    out->workgroup_size = li.workgroup_size;
+    out->lds_bytes_per_workgroup = li.lds_bytes;
+    const unsigned by_lds = li.lds_bytes ? (unsigned)( 160u * 1024u / li.lds_bytes ) : 32u;
+    const unsigned by_waves = 32u * 64u / ( li.workgroup_size ? li.workgroup_size : 64u );
+    out->workgroups_per_cu = by_lds < by_waves ? by_lds : by_waves;
+    out->lattice_mode = li.lattice_mode;
+    out->frames_per_block = li.frames_per_block;
+    out->compute_units = (uint32_t)ctx->ncu;
+    return 0;
 }
 
 namespace {

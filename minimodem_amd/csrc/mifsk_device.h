@@ -66,8 +66,18 @@ int launch_find_frame_batch( const DevCfg &cfg, const DevCfg *d_cfg, const doubl
 	const float *d_samples, const mifsk_search *d_problems,
 	mifsk_search_result *d_results, int nproblems, void *stream );
 
+// what a launcher decided (mifsk_demod_plan): filled instead of launching when
+// the pointer is given
+struct LaunchInfo {
+    const char	*kernel;
+    uint32_t	workgroup_size;
+    uint32_t	lds_bytes;		// dynamic LDS per workgroup
+    uint32_t	lattice_mode;		// LAT_*
+    uint32_t	frames_per_block;	// LATTICE frames scored at once, at most
+};
+
 int launch_demod_batch( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_tw,
-	const mifsk_demod_io &io, void *stream );
+	const mifsk_demod_io &io, void *stream, LaunchInfo *plan_only = nullptr );
 
 // ---- one wavefront per stream (mifsk_wave.hip) ---------------------------
 
@@ -118,7 +128,7 @@ struct WaveHostArgs {
 };
 
 int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_tw,
-	const mifsk_demod_io &io, const WaveHostArgs &ha, void *stream );
+	const mifsk_demod_io &io, const WaveHostArgs &ha, void *stream, LaunchInfo *plan_only = nullptr );
 
 int launch_detect_carrier( const float *d_samples, unsigned nsamples,
 	const double *d_cs /* [fftsize][2] */, unsigned fftsize, unsigned nbands,

@@ -1360,9 +1360,9 @@ static constexpr size_t kLdsHeader = offsetof(StreamLds, slab);
 static constexpr size_t kLdsPerCu = 160 * 1024;
 
 int launch_demod_batch( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_tw,
-	const mifsk_demod_io &io, void *stream )
+	const mifsk_demod_io &io, void *stream, LaunchInfo *plan_only )
 {
-    if ( io.nstreams <= 0 )
+    if ( io.nstreams <= 0 && !plan_only )
 	return 0;
     const uint32_t B = cfg.bit_nsamples;
     // samples one search must see at once
@@ -1457,6 +1457,16 @@ int launch_demod_batch( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_
     }
 
     hipStream_t st = (hipStream_t)stream;
+    if ( plan_only ) {
+	const bool b202 = use_slab && lat_mode == LAT_LINEAR && B == 40u;
+	plan_only->kernel = !use_slab ? "mifsk::demod_kernel<false, 0>"
+			  : b202 ? "mifsk::demod_kernel<true, 10>" : "mifsk::demod_kernel<true, 0>";
+	plan_only->workgroup_size = BLOCK;
+	plan_only->lds_bytes = (uint32_t)( use_slab ? kLdsHeader + slab_floats * 4 : kLdsHeader + 16 );
+	plan_only->lattice_mode = lat_mode;
+	plan_only->frames_per_block = lat_frames * lat_rounds;
+	return 0;
+    }
     if ( use_slab ) {
 	const size_t lds_bytes = kLdsHeader + slab_floats * 4;
 	const bool bell202 = lat_mode == LAT_LINEAR && B == 40u;

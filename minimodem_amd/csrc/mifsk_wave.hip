@@ -1200,9 +1200,9 @@ bool plan_for( const DevCfg &cfg, const WaveHostArgs &ha, int sv, size_t budget,
 } // namespace
 
 int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_tw,
-	const mifsk_demod_io &io, const WaveHostArgs &ha, void *stream )
+	const mifsk_demod_io &io, const WaveHostArgs &ha, void *stream, LaunchInfo *plan_only )
 {
-    if ( io.nstreams <= 0 )
+    if ( io.nstreams <= 0 && !plan_only )
 	return 0;
     const int ncu = ha.ncu > 0 ? ha.ncu : 256;
     // Waves per CU the batch can use (a wave is a workgroup): at least one per
@@ -1261,6 +1261,16 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
     // the instantiation: staging width x resident-table correlator for the bit
     // lengths that have one (linear LATTICE only)
     const uint32_t nq = ( g.lat_mode == LAT_LINEAR && cfg.bit_nsamples % 4u == 0u ) ? cfg.bit_nsamples / 4u : 0u;
+    if ( plan_only ) {
+	plan_only->kernel = plan.sv == 10 ? ( nq == 10u ? "mifsk::demod_wave_kernel<10, 10>"
+					   : nq == 5u ? "mifsk::demod_wave_kernel<10, 5>" : "mifsk::demod_wave_kernel<10, 0>" )
+					  : ( nq == 1u ? "mifsk::demod_wave_kernel<4, 1>" : "mifsk::demod_wave_kernel<4, 0>" );
+	plan_only->workgroup_size = 64;
+	plan_only->lds_bytes = (uint32_t)plan.lds_bytes;
+	plan_only->lattice_mode = g.lat_mode;
+	plan_only->frames_per_block = g.lat_mode != LAT_NONE ? g.lat_fmax : 0u;
+	return 0;
+    }
     hipStream_t st = (hipStream_t)stream;
 #define MIFSK_WAVE_LAUNCH(SV_, NQ_)										\
     do {													\

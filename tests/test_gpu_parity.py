@@ -366,3 +366,23 @@ def test_multi_device_entry_point_shards_and_gathers(gpu):
         assert np.array_equal(res[k], one[k])
     for i in range(11):
         assert np.array_equal(res["bytes"][i, :res["nbytes"][i]], one["bytes"][i, :one["nbytes"][i]])
+
+
+def test_demod_plan_reports_engine_and_lds(gpu):
+    """mifsk_demod_plan: the kernel instantiation, engine and dynamic LDS mifsk_demod_batch uses
+    (rocprofv3 does not report dynamic LDS; this is the occupancy evidence)."""
+    M, torch, ctx = gpu
+    p = M.demod_plan(ctx, M.rx_config("1200"), 1024)
+    assert p["engine"] == "workgroup" and p["workgroup_size"] == 256 and "demod_kernel<true, 10>" in p["kernel"]
+    assert p["lds_bytes_per_workgroup"] <= 40960 and p["workgroups_per_cu"] == 4
+    p = M.demod_plan(ctx, M.rx_config("1200"), 1024, engine="wave")
+    assert p["engine"] == "wave" and "demod_wave_kernel<10, 10>" in p["kernel"] and p["lattice_mode"] == 1
+    p = M.demod_plan(ctx, M.rx_config("12000"), 8192)
+    assert p["engine"] == "wave" and "demod_wave_kernel<4, 1>" in p["kernel"]
+    assert p["workgroups_per_cu"] >= 16 and p["frames_per_block"] >= 32
+    p = M.demod_plan(ctx, M.rx_config("rtty"), 4096)
+    assert p["engine"] == "wave" and p["lattice_mode"] == 0          # half the buffer < one search: no LATTICE
+    p = M.demod_plan(ctx, M.rx_config("1200"), 1024, ring_exact=True)
+    assert p["engine"] == "wave" and p["lattice_mode"] == 0
+    p = M.demod_plan(ctx, M.rx_config("1200", auto_carrier_threshold=0.001), 64)
+    assert p["engine"] == "wave"
