@@ -313,14 +313,15 @@ def test_demod_batch_host_entry_point(gpu, mode, kw, ring):
             assert int(res["carrier_band"][i]) == ref["carrier_band"]
 
 
-def test_output_capacity_overflow_is_flagged(gpu):
+@pytest.mark.parametrize("engine", ["wave", "workgroup"])
+def test_output_capacity_overflow_is_flagged(gpu, engine):
     M, torch, ctx = gpu
     cfg = M.rx_config("1200")
     x = M.synthesize(cfg, b"hello world, this is more than eight frames")
     d = torch.from_numpy(np.pad(x, (0, (-len(x)) % 4))[None, :]).cuda()
     dl = torch.tensor([len(x)], dtype=torch.int32).cuda()
     out = M.demod_batch(ctx, cfg, d, nsamples=dl, want=("bytes", "episodes"), frames_cap=8,
-                        episodes_cap=1)
+                        episodes_cap=1, engine=engine)
     torch.cuda.synchronize()
     r = M.results_to_host(out)
     assert int(r["nframes"][0]) == 43 and int(r["nbytes"][0]) == 43
