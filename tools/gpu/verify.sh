@@ -1,6 +1,6 @@
 set -u
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r02_final; mkdir -p $O
+O=gpurun_out/verify; mkdir -p $O
 timeout 900 python -m pytest tests -m gpu -x -q --timeout 600 > $O/gpu.log 2>&1; echo "rc=$?" >> $O/gpu.log; tail -3 $O/gpu.log
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
 timeout 300 python bench.py > $O/bench.json 2>$O/bench.err; python -c "
