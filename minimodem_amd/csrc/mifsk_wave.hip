@@ -145,6 +145,10 @@ struct Wave {
     uint32_t		lat_n, lat_anchor;
     // how far to speculate: frames per block
     uint32_t		spec, run, cold, pause;
+    // score of candidate 0 (position cursor + try_first, data string) of the scan
+    // just made, reusable by a rescan at the same cursor (scan())
+    FrameOut		k0;
+    bool		k0_valid;
     // register prefetch of the next LINEAR round
     float4		pbuf[SV];
     uint32_t		pref_lo;
@@ -161,7 +165,7 @@ struct Wave {
 	: cfg(c), g(gg), tw(t), x(xs), N(n), mags(m), slab(s), ring(r), lane(threadIdx.x),
 	  safe_limit(safe), slab_lo(0), slab_hi(0), l_conf(0.0f), l_ampl(0.0f), l_bits(0),
 	  lat_n(0), lat_anchor(0), spec(gg.lat_fmin), run(0), cold(0), pause(0),
-	  pref_lo(0xFFFFFFFFu), n_blocks(0), n_scans(0), n_positions(0), n_hits(0), n_stages(0),
+	  k0_valid(false), pref_lo(0xFFFFFFFFu), n_blocks(0), n_scans(0), n_positions(0), n_hits(0), n_stages(0),
 	  cyc_block(0), cyc_scan(0), cyc_stage(0), cyc_corr(0), cyc_conf(0),
 	  cyc_s_stage(0), cyc_s_corr(0), cyc_s_conf(0)
     {
@@ -452,11 +456,18 @@ struct Wave {
 	}
     }
 
+    // `reuse0`: candidate 0 of this scan is the candidate 0 of the scan just made at
+    // the same cursor with the same expect string (the fine rescan after a
+    // carrier-held coarse scan, minimodem.c:1373 after :1265: same try_first, same
+    // data string) -- its score is known and is not computed again.  The
+    // reference computes it twice from the same samples; the result is the same.
     __device__ __forceinline__ ScanResult scan( uint32_t base, const ZigZag &zz, uint32_t first,
-	    float limit, uint32_t kind, bool carrier_held )
+	    float limit, uint32_t kind, bool carrier_held, bool reuse0 = false )
     {
 	ScanResult r;
 	r.conf = 0.0f; r.ampl = 0.0f; r.bits = 0; r.start = 0;
+	if ( !reuse0 )
+	    k0_valid = false;
 	if ( zz.J == 0 )
 	    return r;
 	const uint32_t t0 = MIFSK_WCLOCK();
@@ -464,25 +475,36 @@ struct Wave {
 	// (those are scored against the data string)
 	{
 	    const uint32_t hit = kind == 0u ? lattice_lookup(base + first) : ~0u;
-	    if ( hit != ~0u ) {
-		const float c = lane_bcast(l_conf, hit);
-		if ( c > 0.0f && c >= limit ) {			// fsk.c:492,499
-		    r.conf = c;
-		    r.ampl = lane_bcast(l_ampl, hit);
-		    const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)l_bits, (int)hit);
-		    const uint32_t bhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)( l_bits >> 32 ), (int)hit);
-		    r.bits = ( (uint64_t)bhi << 32 ) | blo;
-		    r.start = first;
-		    n_hits++;
+	    if ( hit != ~0u && !k0_valid ) {
+		k0.conf = lane_bcast(l_conf, hit);
+		k0.ampl = lane_bcast(l_ampl, hit);
+		const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)l_bits, (int)hit);
+		const uint32_t bhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)( l_bits >> 32 ), (int)hit);
+		k0.bits = ( (uint64_t)bhi << 32 ) | blo;
+		k0_valid = true;
+		n_hits++;
+	    }
+	}
+	bool done = false;
+	uint32_t c_begin = 0;
+	if ( k0_valid ) {
+	    // candidate 0 first, as in the scan order (fsk.c:492-501)
+	    if ( r.conf < k0.conf ) {
+		r.conf = k0.conf;
+		r.ampl = k0.ampl;
+		r.bits = k0.bits;
+		r.start = first;
+		if ( r.conf >= limit ) {
+		    cyc_scan += MIFSK_WCLOCK() - t0;
 		    return r;
 		}
 	    }
+	    c_begin = 1;
 	}
 	const uint32_t nb = cfg.n_bits;
 	uint32_t qmax = g.mags_cap / nb;
 	if ( qmax > 64u ) qmax = 64u;
-	bool done = false;
-	for ( uint32_t c0 = 0; c0 < zz.J && !done; c0 += qmax ) {
+	for ( uint32_t c0 = c_begin; c0 < zz.J && !done; c0 += qmax ) {
 	    const uint32_t Q = zz.J - c0 < qmax ? zz.J - c0 : qmax;
 	    // extent of this chunk's candidates, in closed form (see ZigZag)
 	    const uint32_t iend = c0 + Q - 1u;
@@ -523,6 +545,14 @@ struct Wave {
 	    cyc_s_conf += MIFSK_WCLOCK() - ts2;
 	    n_scans++;
 	    n_positions += Q;
+	    if ( c0 == 0u ) {			// candidate 0's own score, for a rescan at this cursor
+		k0.conf = lane_bcast(f.conf, 0);
+		k0.ampl = lane_bcast(f.ampl, 0);
+		const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)f.bits, 0);
+		const uint32_t bhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)( f.bits >> 32 ), 0);
+		k0.bits = ( (uint64_t)bhi << 32 ) | blo;
+		k0_valid = kind == 0u;
+	    }
 	    // fsk.c:492-501 over the chunk, in scan order on lane values
 	    uint32_t win = ~0u;
 	    for ( uint32_t i = 0; i < Q; i++ ) {
@@ -974,7 +1004,9 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 	if ( refine && confidence < INFINITY && try_step > 1u ) {	// minimodem.c:1357-1389
 	    // `carrier` is already set: an acquiring frame is re-searched with
 	    // the data string over the no-carrier range (minimodem.c:1378)
-	    ScanResult s2 = ctx.scan(base, ci ? zf1 : zf0, try_first, INFINITY, 0u, true);
+	    // (with the carrier held before this frame, the coarse scan above used the
+	    // same first try and the same data string: its candidate 0 is reused)
+	    ScanResult s2 = ctx.scan(base, ci ? zf1 : zf0, try_first, INFINITY, 0u, true, ci != 0u);
 	    flags |= MIFSK_FRAME_REFINED;
 	    n_refine++;
 	    if ( s2.conf > confidence ) {
