@@ -88,6 +88,7 @@ struct WaveGeom {
     uint32_t	mags_cap;	// LDS: (mark, space) magnitude slots
     uint32_t	slab_floats;	// LDS: floats in the sample slab
     uint32_t	slab_cap;	// samples a skewed SCAN slab holds (0: SCAN streams from global memory)
+    uint32_t	tiled;		// the slab is a TILE_FLOATS tile: long windows come from global memory through it
     uint32_t	lat_mode;	// LAT_*
     uint32_t	lat_fmax;	// frames per LATTICE block, at most (<= 64)
     uint32_t	lat_fmin;	// ... and at least (one pass of lanes)

@@ -865,6 +865,98 @@ __device__ __forceinline__ void corr_global_stream( const double *__restrict__ t
 	group_bcast_tail(acc, G, s0, s1, s2, s3, left);
 }
 
+// Long windows read from global memory, TILED: one window per lane advancing in
+// lockstep means one load instruction touches 64 different cache lines, which the
+// CU's address path serves at ~1.2 cycles per line (78-90 cycles per
+// global_load_dwordx4, tools/ubench/ta_rate.hip) and which uses 16 of the 128
+// bytes each line fill brings in.  Here the wave fetches TILE_K = 64 samples of
+// every window per step with loads in which 16 adjacent lanes read 256
+// contiguous bytes of ONE window (4 windows per load, 16 cycles each), parks them
+// in an LDS tile -- row w = the 64 samples of window w, rows TILE_ROW floats apart
+// -- and every lane reads its own row back with aligned ds_read_b128 (row stride
+// 68 words: conflict-free in every 16-lane group).  One tile per wave, no
+// barrier: a wave's LDS operations execute in order.  tools/ubench/longwin.hip:
+// 33.7 -> 17.5 ms for the RTTY batch.
+//   a     absolute start of this lane's window (idle lanes: any valid window)
+//   nwin  lanes 0 .. nwin-1 hold windows (uniform); loads for groups of four
+//         lanes beyond that are skipped
+// The caller guarantees a + 16 * ceil(B / 16) <= N for every lane.
+constexpr uint32_t TILE_K = 64u;
+constexpr uint32_t TILE_ROW = TILE_K + 4u;
+constexpr uint32_t TILE_FLOATS = 64u * TILE_ROW;
+
+__device__ __forceinline__ void corr_global_tiled( const double *__restrict__ tw, const float *__restrict__ x,
+	uint32_t a, uint32_t nwin, uint32_t B, uint32_t lane, float *tile, double (&acc)[4] )
+{
+    const uint32_t sub = lane & 15u, grp = lane >> 4;
+    const uint32_t nld = ( nwin + 3u ) >> 2;		// loads per step that carry windows
+    // load i of a step: lanes 16j .. 16j+15 read samples of window 4i + j
+    uint32_t off[16];
+#pragma unroll
+    for ( int i = 0; i < 16; i++ )
+	off[i] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)( ( 4u * (uint32_t)i + grp ) << 2 ), (int)a) + 4u * sub;
+    float *wr = tile + grp * TILE_ROW + 4u * sub;	// + 4 i rows
+    const float *rd = tile + lane * TILE_ROW;
+    const uint32_t ng = ( B + 15u ) >> 4;		// groups of 16 samples
+    const uint32_t nstep = ( ng + 3u ) >> 2;
+    const uint32_t last = B - 16u * ( ng - 1u );	// samples of the last group (1..16)
+    float4 L[16];
+    // (step s carries groups 4s .. min(4s+4, ng)-1: in its last, short step only
+    // the lanes whose 16 bytes fall inside those groups load and store)
+#define MIFSK_TILE_FETCH(S)								\
+    {											\
+	const uint32_t gs_ = ng - 4u * (S) < 4u ? ng - 4u * (S) : 4u;			\
+	if ( sub < 4u * gs_ ) {								\
+	    _Pragma("unroll")								\
+	    for ( int i = 0; i < 16; i++ )						\
+		if ( (uint32_t)i < nld ) {						\
+		    const float4_u v = *reinterpret_cast<const float4_u *>(x + off[i] + TILE_K * (S));	\
+		    L[i] = make_float4(v.x, v.y, v.z, v.w);				\
+		}									\
+	}										\
+    }
+    MIFSK_TILE_FETCH(0u)
+    TwGroup G = tw_group_load(tw, 0, lane);
+    for ( uint32_t s = 0; s < nstep; s++ ) {
+	const uint32_t gs = ng - 4u * s < 4u ? ng - 4u * s : 4u;	// groups in this step
+	if ( sub < 4u * gs ) {
+#pragma unroll
+	    for ( int i = 0; i < 16; i++ )
+		if ( (uint32_t)i < nld )
+		    *reinterpret_cast<float4 *>(wr + 4u * (uint32_t)i * TILE_ROW) = L[i];
+	}
+	if ( s + 1u < nstep )
+	    MIFSK_TILE_FETCH(s + 1u)
+	float4 xa[4], xb[4];
+#pragma unroll
+	for ( int j = 0; j < 4; j++ )
+	    xa[j] = *reinterpret_cast<const float4 *>(rd + 4 * j);
+#pragma unroll
+	for ( int h = 0; h < 4; h++ ) {
+	    if ( (uint32_t)h < gs ) {
+		const uint32_t g = 4u * s + (uint32_t)h;
+		TwGroup Gn = G;
+		if ( g + 1u < ng )
+		    Gn = tw_group_load(tw, g + 1u, lane);
+		float4 ( &cur )[4] = ( h & 1 ) ? xb : xa;
+		float4 ( &nxt )[4] = ( h & 1 ) ? xa : xb;
+		if ( (uint32_t)h + 1u < gs ) {
+#pragma unroll
+		    for ( int j = 0; j < 4; j++ )
+			nxt[j] = *reinterpret_cast<const float4 *>(rd + 16 * ( h + 1 ) + 4 * j);
+		}
+		dpp_settle();
+		if ( g + 1u < ng || last >= 16u )
+		    group_bcast(acc, G, cur[0], cur[1], cur[2], cur[3]);
+		else
+		    group_bcast_tail(acc, G, cur[0], cur[1], cur[2], cur[3], last);
+		G = Gn;
+	    }
+	}
+    }
+#undef MIFSK_TILE_FETCH
+}
+
 // Window held in a SKEWED slab (rows of one bit length, `skew` pad words in
 // between; see store4_skewed), starting `rel` samples after slab row 0: one
 // ds_read_b32 per sample, 16 at a time.

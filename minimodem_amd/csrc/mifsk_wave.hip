@@ -123,6 +123,11 @@ __device__ __forceinline__ int wave_detect_window( const float *__restrict__ w, 
 }
 
 // everything the kernel keeps per stream beyond the loop's scalars
+// NQ: > 0 = the resident-table correlator for windows of 4 NQ samples (linear
+// LATTICE); 0 = any bit length; kTiled = the instantiation for long windows
+// read from global memory through the LDS tile (no linear LATTICE in it)
+constexpr int kTiled = -1;
+
 template <int SV, int NQ>
 struct Wave {
     static constexpr uint32_t kRoundFloats = 64u * SV * 4u;	// samples one staging round loads
@@ -309,7 +314,10 @@ struct Wave {
 	const uint32_t Bpad = ( B + 15u ) & ~15u;		// whole groups of 16 are loaded
 	double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
 	if ( __all(a + Bpad <= N && a + Bpad >= a) ) {
-	    corr_global_stream(tw, x + a, B, lane, acc);
+	    if constexpr ( NQ == kTiled )
+		corr_global_tiled(tw, x, a, nw < 64u ? nw : 64u, B, lane, slab, acc);
+	    else
+		corr_global_stream(tw, x + a, B, lane, acc);
 	} else {
 	    // a window reaches the end of the stream: per-sample guarded reads
 	    for ( uint32_t n = 0; n < B; n++ ) {
@@ -332,7 +340,7 @@ struct Wave {
 	const uint32_t t0 = MIFSK_WCLOCK();
 	const uint32_t nb = cfg.n_bits;
 	const uint32_t W = cfg.lat_grid ? F * ( nb - 1u ) + 1u : F * nb;
-	if ( g.lat_mode == LAT_LINEAR ) {
+	if ( NQ != kTiled && g.lat_mode == LAT_LINEAR ) {
 	    const uint32_t rw = g.round_wins;
 	    for ( uint32_t w0 = 0; w0 < W; w0 += rw ) {
 		const uint32_t nw = W - w0 < rw ? W - w0 : rw;
@@ -436,9 +444,13 @@ struct Wave {
 	    if ( use_slab ) {
 		corr_skewed_stream(cfg, tw, slab, a - slab_lo, lane, acc);
 	    } else if ( !ring && __all(a + ( ( B + 15u ) & ~15u ) <= N && a + B + 16u >= a) ) {
-		// long windows (or no slab at this occupancy): stream from global
-		// memory, 64 bytes per lane per 16 samples, next group in flight
-		corr_global_stream(tw, x + a, B, lane, acc);
+		// long windows (or no slab at this occupancy): from global memory,
+		// through the LDS tile where there is one, else 64 bytes per lane per
+		// 16 samples with the next group in flight
+		if constexpr ( NQ == kTiled )
+		    corr_global_tiled(tw, x, a, nwin - w0 < 64u ? nwin - w0 : 64u, B, lane, slab, acc);
+		else
+		    corr_global_stream(tw, x + a, B, lane, acc);
 	    } else {
 		for ( uint32_t n = 0; n < B; n++ ) {
 		    const uint32_t idx = a + n;
@@ -1136,7 +1148,8 @@ inline uint32_t rel_of( const DevCfg &cfg, uint32_t w )
 
 // Geometry for a staging width `sv` within `budget` bytes of LDS per wave;
 // false when it does not fit.
-bool plan_for( const DevCfg &cfg, const WaveHostArgs &ha, int sv, size_t budget, Plan &out )
+bool plan_for( const DevCfg &cfg, const WaveHostArgs &ha, int sv, size_t budget, Plan &out,
+	       bool want_tile = false )
 {
     const uint32_t B = cfg.bit_nsamples, nb = cfg.n_bits;
     WaveGeom g;
@@ -1199,7 +1212,14 @@ bool plan_for( const DevCfg &cfg, const WaveHostArgs &ha, int sv, size_t budget,
 	uint32_t mcap = g.lat_mode != LAT_NONE ? wins_of(cfg, g.lat_fmax) : 0u;
 	if ( mcap < 16u * nb ) mcap = 16u * nb;
 	g.mags_cap = ( mcap + 1u ) & ~1u;
-	const size_t sf = scan_floats > region_floats ? scan_floats : region_floats;
+	size_t sf = scan_floats > region_floats ? scan_floats : region_floats;
+	// no SCAN slab: long windows go through a tile instead (corr_global_tiled)
+	g.tiled = ( scan_floats == 0 && want_tile && !ha.ring_exact && B >= TILE_K ) ? 1u : 0u;
+	if ( g.tiled ) {
+	    if ( g.lat_mode == LAT_LINEAR )
+		g.lat_mode = LAT_DIRECT;	// (that instantiation has no staged rounds)
+	    sf = TILE_FLOATS;
+	}
 	const size_t total = (size_t)g.mags_cap * sizeof(float2) + sf * 4u + 16u;
 	if ( total <= budget ) {
 	    g.slab_floats = (uint32_t)sf;
@@ -1263,9 +1283,16 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
 	if ( wpc == 4u )
 	    break;
     }
+    if ( !ok && force_sv != 4 ) {
+	// nothing keeps the SCAN slab in LDS (RTTY: 1056-sample windows, a 40 kB
+	// span; 0.5 baud: 96000-sample windows): the windows come from global
+	// memory through a 17 kB tile, two waves per SIMD
+	const uint32_t wpc = want < 8u ? want : 8u;
+	const size_t budget = ( kLdsPerCu / wpc ) & ~(size_t)255;
+	ok = plan_for(cfg, ha, 10, budget, plan, true) && plan.g.tiled;
+    }
     if ( !ok ) {
-	// nothing keeps the SCAN slab in LDS (0.5 baud: 96000-sample windows):
-	// stream from global memory
+	// ... or straight into registers, a window per lane
 	const size_t budget = ( kLdsPerCu / want ) & ~(size_t)255;
 	ok = plan_for(cfg, ha, 4, budget, plan);
 	if ( !ok )
@@ -1294,7 +1321,8 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
     // lengths that have one (linear LATTICE only)
     const uint32_t nq = ( g.lat_mode == LAT_LINEAR && cfg.bit_nsamples % 4u == 0u ) ? cfg.bit_nsamples / 4u : 0u;
     if ( plan_only ) {
-	plan_only->kernel = plan.sv == 10 ? ( nq == 10u ? "mifsk::demod_wave_kernel<10, 10>"
+	plan_only->kernel = g.tiled ? "mifsk::demod_wave_kernel<10, -1>"
+			  : plan.sv == 10 ? ( nq == 10u ? "mifsk::demod_wave_kernel<10, 10>"
 					   : nq == 5u ? "mifsk::demod_wave_kernel<10, 5>" : "mifsk::demod_wave_kernel<10, 0>" )
 					  : ( nq == 1u ? "mifsk::demod_wave_kernel<4, 1>" : "mifsk::demod_wave_kernel<4, 0>" );
 	plan_only->workgroup_size = 64;
@@ -1313,7 +1341,9 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
 	hipLaunchKernelGGL((demod_wave_kernel<SV_, NQ_>), dim3((unsigned)io.nstreams), dim3(64),		\
 			   plan.lds_bytes, st, d_cfg, d_tw, io, g, au);						\
     } while (0)
-    if ( plan.sv == 10 ) {
+    if ( g.tiled ) {
+	MIFSK_WAVE_LAUNCH(10, kTiled);				// RTTY and slower
+    } else if ( plan.sv == 10 ) {
 	if ( nq == 10u )     MIFSK_WAVE_LAUNCH(10, 10);		// 1200 baud at 48 kHz
 	else if ( nq == 5u ) MIFSK_WAVE_LAUNCH(10, 5);		// 2400 baud; 1200 baud at 24 kHz
 	else                 MIFSK_WAVE_LAUNCH(10, 0);
