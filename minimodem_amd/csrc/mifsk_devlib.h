@@ -877,84 +877,121 @@ __device__ __forceinline__ void corr_global_stream( const double *__restrict__ t
 // 68 words: conflict-free in every 16-lane group).  One tile per wave, no
 // barrier: a wave's LDS operations execute in order.  tools/ubench/longwin.hip:
 // 33.7 -> 17.5 ms for the RTTY batch.
-//   a     absolute start of this lane's window (idle lanes: any valid window)
-//   nwin  lanes 0 .. nwin-1 hold windows (uniform); loads for groups of four
-//         lanes beyond that are skipped
-// The caller guarantees a + 16 * ceil(B / 16) <= N for every lane.
 constexpr uint32_t TILE_K = 64u;
 constexpr uint32_t TILE_ROW = TILE_K + 4u;
 constexpr uint32_t TILE_FLOATS = 64u * TILE_ROW;
 
-__device__ __forceinline__ void corr_global_tiled( const double *__restrict__ tw, const float *__restrict__ x,
-	uint32_t a, uint32_t nwin, uint32_t B, uint32_t lane, float *tile, double (&acc)[4] )
+// NLD loads per step: windows 0 .. 4 NLD - 1.  Straight-line steps: every load and
+// store of a step is unconditional (a conditional load leaves the compiler with
+// an outstanding counter at the join and it waits for everything there).
+template <int NLD>
+__device__ __forceinline__ void corr_global_tiled_n( const double *__restrict__ tw, const float *__restrict__ x,
+	uint32_t a, uint32_t B, uint32_t lane, float *tile, double (&acc)[4] )
 {
     const uint32_t sub = lane & 15u, grp = lane >> 4;
-    const uint32_t nld = ( nwin + 3u ) >> 2;		// loads per step that carry windows
     // load i of a step: lanes 16j .. 16j+15 read samples of window 4i + j
-    uint32_t off[16];
+    uint32_t off[NLD];
 #pragma unroll
-    for ( int i = 0; i < 16; i++ )
+    for ( int i = 0; i < NLD; i++ )
 	off[i] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)( ( 4u * (uint32_t)i + grp ) << 2 ), (int)a) + 4u * sub;
     float *wr = tile + grp * TILE_ROW + 4u * sub;	// + 4 i rows
     const float *rd = tile + lane * TILE_ROW;
-    const uint32_t ng = ( B + 15u ) >> 4;		// groups of 16 samples
-    const uint32_t nstep = ( ng + 3u ) >> 2;
-    const uint32_t last = B - 16u * ( ng - 1u );	// samples of the last group (1..16)
-    float4 L[16];
-    // (step s carries groups 4s .. min(4s+4, ng)-1: in its last, short step only
-    // the lanes whose 16 bytes fall inside those groups load and store)
+    const uint32_t ngf = B >> 4;			// whole groups of 16 samples
+    const uint32_t tail = B & 15u;			// samples of the last, short group
+    const uint32_t nfull = ngf >> 2;			// steps of four whole groups
+    const uint32_t rest = ngf & 3u;			// whole groups of the last, short step
+    const uint32_t last_step = ( rest | tail ) ? nfull : nfull - 1u;
+    float4 L[NLD];
 #define MIFSK_TILE_FETCH(S)								\
-    {											\
-	const uint32_t gs_ = ng - 4u * (S) < 4u ? ng - 4u * (S) : 4u;			\
-	if ( sub < 4u * gs_ ) {								\
-	    _Pragma("unroll")								\
-	    for ( int i = 0; i < 16; i++ )						\
-		if ( (uint32_t)i < nld ) {						\
-		    const float4_u v = *reinterpret_cast<const float4_u *>(x + off[i] + TILE_K * (S));	\
-		    L[i] = make_float4(v.x, v.y, v.z, v.w);				\
-		}									\
-	}										\
+    _Pragma("unroll")									\
+    for ( int i = 0; i < NLD; i++ ) {							\
+	const float4_u v = *reinterpret_cast<const float4_u *>(x + off[i] + TILE_K * (S));	\
+	L[i] = make_float4(v.x, v.y, v.z, v.w);						\
     }
+#define MIFSK_TILE_WRITE()								\
+    _Pragma("unroll")									\
+    for ( int i = 0; i < NLD; i++ )							\
+	*reinterpret_cast<float4 *>(wr + 4u * (uint32_t)i * TILE_ROW) = L[i];
+#define MIFSK_TILE_READ(XS, H)								\
+    _Pragma("unroll")									\
+    for ( int j = 0; j < 4; j++ )							\
+	XS[j] = *reinterpret_cast<const float4 *>(rd + 16 * (H) + 4 * j);
     MIFSK_TILE_FETCH(0u)
     TwGroup G = tw_group_load(tw, 0, lane);
-    for ( uint32_t s = 0; s < nstep; s++ ) {
-	const uint32_t gs = ng - 4u * s < 4u ? ng - 4u * s : 4u;	// groups in this step
-	if ( sub < 4u * gs ) {
-#pragma unroll
-	    for ( int i = 0; i < 16; i++ )
-		if ( (uint32_t)i < nld )
-		    *reinterpret_cast<float4 *>(wr + 4u * (uint32_t)i * TILE_ROW) = L[i];
-	}
-	if ( s + 1u < nstep )
-	    MIFSK_TILE_FETCH(s + 1u)
+    for ( uint32_t s = 0; s < nfull; s++ ) {
+	MIFSK_TILE_WRITE()
+	const uint32_t sn = s < last_step ? s + 1u : last_step;		// (the last step is fetched twice)
+	MIFSK_TILE_FETCH(sn)
 	float4 xa[4], xb[4];
+	MIFSK_TILE_READ(xa, 0)
+	// (the table is padded by a group: loading group g + 1 is always legal)
+	{
+	    const TwGroup Gn = tw_group_load(tw, 4u * s + 1u, lane);
+	    MIFSK_TILE_READ(xb, 1)
+	    dpp_settle();
+	    group_bcast(acc, G, xa[0], xa[1], xa[2], xa[3]);
+	    G = Gn;
+	}
+	{
+	    const TwGroup Gn = tw_group_load(tw, 4u * s + 2u, lane);
+	    MIFSK_TILE_READ(xa, 2)
+	    dpp_settle();
+	    group_bcast(acc, G, xb[0], xb[1], xb[2], xb[3]);
+	    G = Gn;
+	}
+	{
+	    const TwGroup Gn = tw_group_load(tw, 4u * s + 3u, lane);
+	    MIFSK_TILE_READ(xb, 3)
+	    dpp_settle();
+	    group_bcast(acc, G, xa[0], xa[1], xa[2], xa[3]);
+	    G = Gn;
+	}
+	{
+	    const TwGroup Gn = tw_group_load(tw, 4u * s + 4u, lane);
+	    dpp_settle();
+	    group_bcast(acc, G, xb[0], xb[1], xb[2], xb[3]);
+	    G = Gn;
+	}
+    }
+    if ( rest | tail ) {
+	// the short step: `rest` whole groups, then `tail` samples
+	MIFSK_TILE_WRITE()
+	float4 xs[4];
+	for ( uint32_t h = 0; h < rest; h++ ) {
+	    const TwGroup Gn = tw_group_load(tw, 4u * nfull + h + 1u, lane);
+	    const float *r = rd + 16u * h;
 #pragma unroll
-	for ( int j = 0; j < 4; j++ )
-	    xa[j] = *reinterpret_cast<const float4 *>(rd + 4 * j);
+	    for ( int j = 0; j < 4; j++ )
+		xs[j] = *reinterpret_cast<const float4 *>(r + 4 * j);
+	    dpp_settle();
+	    group_bcast(acc, G, xs[0], xs[1], xs[2], xs[3]);
+	    G = Gn;
+	}
+	if ( tail ) {
+	    const float *r = rd + 16u * rest;
 #pragma unroll
-	for ( int h = 0; h < 4; h++ ) {
-	    if ( (uint32_t)h < gs ) {
-		const uint32_t g = 4u * s + (uint32_t)h;
-		TwGroup Gn = G;
-		if ( g + 1u < ng )
-		    Gn = tw_group_load(tw, g + 1u, lane);
-		float4 ( &cur )[4] = ( h & 1 ) ? xb : xa;
-		float4 ( &nxt )[4] = ( h & 1 ) ? xa : xb;
-		if ( (uint32_t)h + 1u < gs ) {
-#pragma unroll
-		    for ( int j = 0; j < 4; j++ )
-			nxt[j] = *reinterpret_cast<const float4 *>(rd + 16 * ( h + 1 ) + 4 * j);
-		}
-		dpp_settle();
-		if ( g + 1u < ng || last >= 16u )
-		    group_bcast(acc, G, cur[0], cur[1], cur[2], cur[3]);
-		else
-		    group_bcast_tail(acc, G, cur[0], cur[1], cur[2], cur[3], last);
-		G = Gn;
-	    }
+	    for ( int j = 0; j < 4; j++ )
+		xs[j] = *reinterpret_cast<const float4 *>(r + 4 * j);
+	    dpp_settle();
+	    group_bcast_tail(acc, G, xs[0], xs[1], xs[2], xs[3], tail);
 	}
     }
 #undef MIFSK_TILE_FETCH
+#undef MIFSK_TILE_WRITE
+#undef MIFSK_TILE_READ
+}
+
+//   a     absolute start of this lane's window (idle lanes: any valid window)
+//   nwin  lanes 0 .. nwin-1 hold windows (uniform)
+// The caller guarantees a + 64 * ceil(B / 64) <= N for every lane (whole steps
+// are loaded; what lies beyond B is not accumulated).
+__device__ __forceinline__ void corr_global_tiled( const double *__restrict__ tw, const float *__restrict__ x,
+	uint32_t a, uint32_t nwin, uint32_t B, uint32_t lane, float *tile, double (&acc)[4] )
+{
+    if ( nwin > 32u )
+	corr_global_tiled_n<16>(tw, x, a, B, lane, tile, acc);
+    else
+	corr_global_tiled_n<8>(tw, x, a, B, lane, tile, acc);
 }
 
 // Window held in a SKEWED slab (rows of one bit length, `skew` pad words in

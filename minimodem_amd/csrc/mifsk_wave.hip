@@ -311,7 +311,8 @@ struct Wave {
 	const uint32_t w = w0 + lane;
 	const bool active = lane < nw;
 	const uint32_t a = A + win_rel(active ? w : w0);
-	const uint32_t Bpad = ( B + 15u ) & ~15u;		// whole groups of 16 are loaded
+	// whole groups of 16 (tile: steps of 64) are loaded
+	const uint32_t Bpad = NQ == kTiled ? ( ( B + 63u ) & ~63u ) : ( ( B + 15u ) & ~15u );
 	double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
 	if ( __all(a + Bpad <= N && a + Bpad >= a) ) {
 	    if constexpr ( NQ == kTiled )
@@ -443,7 +444,8 @@ struct Wave {
 	    double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
 	    if ( use_slab ) {
 		corr_skewed_stream(cfg, tw, slab, a - slab_lo, lane, acc);
-	    } else if ( !ring && __all(a + ( ( B + 15u ) & ~15u ) <= N && a + B + 16u >= a) ) {
+	    } else if ( !ring && __all(a + ( NQ == kTiled ? ( ( B + 63u ) & ~63u ) : ( ( B + 15u ) & ~15u ) ) <= N
+				       && a + B + 64u >= a) ) {
 		// long windows (or no slab at this occupancy): from global memory,
 		// through the LDS tile where there is one, else 64 bytes per lane per
 		// 16 samples with the next group in flight
