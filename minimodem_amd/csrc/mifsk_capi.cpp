@@ -52,8 +52,54 @@ void fill_devcfg( DevCfg &d, const mifsk_rx_config &c )
     d.rx_one = c.rx_one ? 1u : 0u;
     d.sync_byte = c.sync_byte;
     d.b_mark = c.b_mark;
-    // odd row pitch => lanes one bit apart never share an LDS bank
-    d.skew = ( c.bit_nsamples & 1u ) ? 0u : 1u;
+    // One pad word per bit row of a SCAN slab where that spreads the lanes of a
+    // search over more LDS banks: the first 64 windows of the carrier-held fine
+    // search (lane = candidate * n_bits + bit, ds_read_b32, 32 lanes per LDS
+    // cycle, bank = word mod 32) are laid out both ways and the cheaper pitch
+    // wins; unpadded rows on a tie (no per-sample row test in the correlator).
+    {
+	auto cost = [&]( unsigned skew ) -> unsigned {
+	    const unsigned f = c.try_first[1], mx = c.try_max[1], st = c.try_step_fine[1];
+	    const unsigned nb = c.expect_n_bits ? c.expect_n_bits : 1u, B = c.bit_nsamples ? c.bit_nsamples : 1u;
+	    unsigned U = 0, D = 0;
+	    if ( f < mx && st ) {
+		U = ( mx - f - 1 ) / st + 1;
+		D = U - 1 < f / st ? U - 1 : f / st;
+	    }
+	    const unsigned J = U + D;
+	    unsigned word[64], n = 0;
+	    for ( unsigned i = 0; i < J && n < 64; i++ ) {
+		unsigned t = f;
+		if ( i && i <= 2 * D )
+		    t = ( i & 1u ) ? f + ( ( i + 1 ) / 2 ) * st : f - ( ( i + 1 ) / 2 ) * st;
+		else if ( i )
+		    t = f + ( i - D ) * st;
+		for ( unsigned k = 0; k < nb && n < 64; k++ ) {
+		    const unsigned rel = t + c.bit_offset[k];
+		    word[n++] = rel + ( rel / B ) * skew;
+		}
+	    }
+	    unsigned total = 0;
+	    for ( unsigned h = 0; h < n; h += 32 ) {
+		unsigned worst = 0;
+		for ( unsigned bank = 0; bank < 32; bank++ ) {
+		    unsigned distinct = 0;
+		    for ( unsigned i = h; i < n && i < h + 32; i++ ) {
+			if ( word[i] % 32 != bank )
+			    continue;
+			bool seen = false;
+			for ( unsigned j = h; j < i; j++ )
+			    seen = seen || word[j] == word[i];
+			distinct += seen ? 0u : 1u;
+		    }
+		    worst = distinct > worst ? distinct : worst;
+		}
+		total += worst;
+	    }
+	    return total;
+	};
+	d.skew = cost(1) < cost(0) ? 1u : 0u;
+    }
     d.div_magic = c.bit_nsamples > 1 ? (uint32_t)( 0x100000000ULL / c.bit_nsamples ) : 0xFFFFFFFFu;
     // minimodem.c:1407 with frame_start == try_first (carrier)
     d.lock_advance = c.try_first[1] + c.frame_nsamples - c.nsamples_overscan;

@@ -994,12 +994,55 @@ __device__ __forceinline__ void corr_global_tiled( const double *__restrict__ tw
 	corr_global_tiled_n<8>(tw, x, a, B, lane, tile, acc);
 }
 
+// Window in a slab WITHOUT pad words (cfg.skew == 0), at any alignment: the
+// sample addresses are the window start plus constants, no per-sample row test.
+__device__ __forceinline__ void corr_slab_plain( const double *__restrict__ tw, const float *p, uint32_t B,
+	uint32_t lane, double (&acc)[4] )
+{
+    const uint32_t ng = ( B + 15u ) >> 4;
+    const uint32_t last = B - 1u;
+    TwGroup G = tw_group_load(tw, 0, lane);
+    for ( uint32_t g = 0; g + 1u < ng; g++ ) {
+	const TwGroup Gn = tw_group_load(tw, g + 1u, lane);
+	const float *q = p + 16u * g;
+	float xs[16];
+#pragma unroll
+	for ( int j = 0; j < 16; j++ )
+	    xs[j] = q[j];
+	dpp_settle();
+	group_bcast(acc, G, make_float4(xs[0], xs[1], xs[2], xs[3]), make_float4(xs[4], xs[5], xs[6], xs[7]),
+		    make_float4(xs[8], xs[9], xs[10], xs[11]), make_float4(xs[12], xs[13], xs[14], xs[15]));
+	G = Gn;
+    }
+    {
+	float xs[16];
+#pragma unroll
+	for ( int j = 0; j < 16; j++ ) {
+	    uint32_t n = 16u * ( ng - 1u ) + (uint32_t)j;
+	    n = n < last ? n : last;			// (uniform) never past the window
+	    xs[j] = p[n];
+	}
+	const float4 s0 = make_float4(xs[0], xs[1], xs[2], xs[3]), s1 = make_float4(xs[4], xs[5], xs[6], xs[7]);
+	const float4 s2 = make_float4(xs[8], xs[9], xs[10], xs[11]), s3 = make_float4(xs[12], xs[13], xs[14], xs[15]);
+	const uint32_t left = B - 16u * ( ng - 1u );
+	dpp_settle();
+	if ( left >= 16u )
+	    group_bcast(acc, G, s0, s1, s2, s3);
+	else
+	    group_bcast_tail(acc, G, s0, s1, s2, s3, left);
+    }
+}
+
 // Window held in a SKEWED slab (rows of one bit length, `skew` pad words in
 // between; see store4_skewed), starting `rel` samples after slab row 0: one
 // ds_read_b32 per sample, 16 at a time.
 __device__ __forceinline__ void corr_skewed_stream( const DevCfg &cfg, const double *__restrict__ tw,
 	const float *slab, uint32_t rel, uint32_t lane, double (&acc)[4] )
 {
+    if ( cfg.skew == 0u ) {
+	corr_slab_plain(tw, slab + rel, cfg.bit_nsamples, lane, acc);
+	return;
+    }
     const uint32_t B = cfg.bit_nsamples;
     uint32_t row, col;
     divmod_bit(cfg, rel, row, col);

@@ -522,6 +522,12 @@ int main( int argc, char **argv )
 	printf("%-40s %8.2f ms\n", name, ms);
 	fflush(stdout);
     };
+    for ( size_t l : { (size_t)10240, (size_t)18448, (size_t)19968, (size_t)20480, (size_t)24576 } ) {
+	int nb = 0;
+	CK(hipFuncSetAttribute((const void *)k_tiledK<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+	CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_tiledK<64, false>, 64, l));
+	printf("occupancy query: k_tiledK<64> with %zu bytes of LDS: %d workgroups per CU\n", l, nb);
+    }
     run("arithmetic only (261 passes), with cvt", [&] { hipLaunchKernelGGL(k_compute<true>, dim3(nstreams), dim3(64), 0, 0, tw, 261, out); });
     run("arithmetic only (261 passes), cvt hoisted", [&] { hipLaunchKernelGGL(k_compute<false>, dim3(nstreams), dim3(64), 0, 0, tw, 261, out); });
     run("arithmetic + global loads (unused)", [&] { hipLaunchKernelGGL(k_mix<1>, dim3(nstreams), dim3(64), 8192, 0, x, stride, tw, nframes, out, cstep, fstep); });
