@@ -329,6 +329,7 @@ struct Master {
     // scored lattice frames held in lds->c_conf/c_ampl/c_bits[0 .. lat_n): entry e
     // is the frame whose first try sits at lat_anchor + e * lock_advance
     uint32_t		lat_n, lat_anchor;
+    uint32_t		hit_base = 0xFFFFFFFFu;	// cursor of the last scan a lattice frame answered
     // work counters (written out only when the caller asked for them)
     uint32_t		n_batches = 0, n_stages = 0, n_hits = 0, n_positions = 0, n_lattice = 0;
     uint32_t		cyc_par = 0, cyc_conf = 0, cyc_wait = 0, cyc_scan_wait = 0;
@@ -489,12 +490,116 @@ struct Master {
 	cyc_conf += MIFSK_CLOCK() - t_conf;
     }
 
+    // The carrier-held fine rescan (minimodem.c:1357-1389) of a frame whose first
+    // try -- candidate 0 of both scans -- is a scored lattice frame, run by this
+    // wave ALONE: the other candidates' windows all lie within a few hundred
+    // samples, which the wave fetches in one coalesced sweep into the magnitude
+    // buffer no batch is using; each lane then reads its window from there
+    // (tables in registers), scores and selects in registers.  No slab, no
+    // barrier, nothing of the lattice state touched: the workers go on with the
+    // batch in flight, which stays good when the rescan confirms the position.
+    // Windows of 4 NQ samples; false when this does not apply (the caller then
+    // takes the general route).
+    template <int NQ>
+    __device__ __forceinline__ bool solo_fine( uint32_t base, const ZigZag &zz, uint32_t first,
+	    const ScanResult &c0, ScanResult &r )
+    {
+	static_assert(NQ >= 1 && NQ <= 12, "three table groups");
+	constexpr uint32_t B = 4u * NQ;
+	const uint32_t nb = cfg.n_bits;
+	const uint32_t nwin = ( zz.J - 1u ) * nb;
+	if ( zz.J < 2u || nwin > 128u || zz.J - 1u > 64u )
+	    return false;
+	// what the candidates read, rounded out to whole float4
+	const uint32_t lo = base + first - zz.D * zz.step + cfg.bit_offset[0];
+	const uint32_t hi = base + first + ( zz.U - 1u ) * zz.step + cfg.bit_offset[( nb - 1u ) & 63u] + B;
+	const uint32_t org4 = lo & ~3u;
+	const uint32_t nvec = ( hi - org4 + 3u ) >> 2;
+	if ( hi > N || hi < lo || org4 + 4u * nvec > N || nvec > 128u
+		|| nvec * 16u + nwin * sizeof(float2) > sizeof(lds->mags[0]) )
+	    return false;
+	// the buffer the batch in flight does NOT fill has been scored already
+	// (lattice_advance): samples first, then this search's magnitudes
+	float *sbuf = reinterpret_cast<float *>(lds->mags[inflight ? ( inflight_buf ^ 1u ) : 0u]);
+	float2 *sm = reinterpret_cast<float2 *>(sbuf + 4u * nvec);
+	{
+	    const bool h0 = lane < nvec, h1 = lane + 64u < nvec;
+	    float4_u v0, v1;
+	    if ( h0 ) v0 = *reinterpret_cast<const float4_u *>(x + org4 + 4u * lane);
+	    if ( h1 ) v1 = *reinterpret_cast<const float4_u *>(x + org4 + 4u * ( lane + 64u ));
+	    if ( h0 ) *reinterpret_cast<float4 *>(sbuf + 4u * lane) = make_float4(v0.x, v0.y, v0.z, v0.w);
+	    if ( h1 ) *reinterpret_cast<float4 *>(sbuf + 4u * ( lane + 64u )) = make_float4(v1.x, v1.y, v1.z, v1.w);
+	}
+	TwGroup tg[3];
+#pragma unroll
+	for ( int gi = 0; gi < ( NQ + 3 ) / 4; gi++ )
+	    tg[gi] = tw_group_load(tw, (uint32_t)gi, lane);
+	wave_lds_sync();
+	for ( uint32_t w0 = 0; w0 < nwin; w0 += 64u ) {
+	    const uint32_t w = w0 + lane;
+	    const bool active = w < nwin;
+	    const uint32_t q = active ? udiv_magic(w, nb, cfg.nbits_magic) : 0u;
+	    const uint32_t k = active ? w - q * nb : 0u;
+	    const float *p = sbuf + ( base + zz.at(1u + q) + cfg.bit_offset[k & 63u] - org4 );
+	    float4 xs[NQ];
+#pragma unroll
+	    for ( int i = 0; i < NQ; i++ )
+		xs[i] = make_float4(p[4 * i], p[4 * i + 1], p[4 * i + 2], p[4 * i + 3]);
+	    double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
+	    dpp_settle();
+#define MIFSK_SOLO_QUAD(Q)								\
+	    if ( (Q) < NQ ) {								\
+		if ( (Q) % 4 == 0 ) quad_bcast<0>(acc, tg[(Q) / 4], xs[(Q) < NQ ? (Q) : 0]);	\
+		if ( (Q) % 4 == 1 ) quad_bcast<4>(acc, tg[(Q) / 4], xs[(Q) < NQ ? (Q) : 0]);	\
+		if ( (Q) % 4 == 2 ) quad_bcast<8>(acc, tg[(Q) / 4], xs[(Q) < NQ ? (Q) : 0]);	\
+		if ( (Q) % 4 == 3 ) quad_bcast<12>(acc, tg[(Q) / 4], xs[(Q) < NQ ? (Q) : 0]);	\
+	    }
+	    MIFSK_SOLO_QUAD(0) MIFSK_SOLO_QUAD(1) MIFSK_SOLO_QUAD(2) MIFSK_SOLO_QUAD(3)
+	    MIFSK_SOLO_QUAD(4) MIFSK_SOLO_QUAD(5) MIFSK_SOLO_QUAD(6) MIFSK_SOLO_QUAD(7)
+	    MIFSK_SOLO_QUAD(8) MIFSK_SOLO_QUAD(9) MIFSK_SOLO_QUAD(10) MIFSK_SOLO_QUAD(11)
+#undef MIFSK_SOLO_QUAD
+	    if ( active )
+		sm[w] = make_float2(band_mag(acc[0], acc[1], cfg.magscalar),
+				    band_mag(acc[2], acc[3], cfg.magscalar));
+	}
+	wave_lds_sync();
+	FrameOut f;
+	f.conf = 0.0f; f.ampl = 0.0f; f.bits = 0;
+	if ( lane < zz.J - 1u )
+	    f = frame_confidence_any(&sm[lane * nb], cfg.req_mask[0], cfg.req_val[0], nb);
+	n_positions += zz.J - 1u;
+	// fsk.c:492-501 in scan order, candidate 0 first; the limit of this scan
+	// is INFINITY (minimodem.c:1367)
+	r = c0;
+	uint32_t win = 0;
+	if ( !( r.conf >= INFINITY ) ) {
+	    for ( uint32_t i = 1; i < zz.J; i++ ) {
+		const float c = lane_bcast(f.conf, i - 1u);
+		if ( r.conf < c ) {
+		    r.conf = c;
+		    win = i;
+		    if ( r.conf >= INFINITY )
+			break;
+		}
+	    }
+	}
+	if ( win ) {
+	    r.ampl = lane_bcast(f.ampl, win - 1u);
+	    const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)f.bits, (int)( win - 1u ));
+	    const uint32_t bhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)( f.bits >> 32 ), (int)( win - 1u ));
+	    r.bits = ( (uint64_t)bhi << 32 ) | blo;
+	    r.start = zz.at(win);
+	}
+	return true;
+    }
+
     // fsk_find_frame at cursor `base` (absolute)
     __device__ __forceinline__ ScanResult scan( uint32_t base, const ZigZag &zz, uint32_t first,
 	    float limit, uint32_t kind )
     {
 	ScanResult r;
 	r.conf = 0.0f; r.ampl = 0.0f; r.bits = 0; r.start = 0;
+	hit_base = 0xFFFFFFFFu;
 	if ( zz.J == 0 )
 	    return r;
 	const uint32_t p0 = base + first;
@@ -511,6 +616,7 @@ struct Master {
 		    r.bits = lds->c_bits[hit];
 		    r.start = first;
 		    n_hits++;
+		    hit_base = base;		// (candidate 0 of a rescan at this cursor is this frame)
 		    return r;
 		}
 	    }
@@ -573,7 +679,7 @@ struct StreamOut {
 
 
 // The reference's receive loop (minimodem.c:1137-1463); executed by wave 0 only.
-template <bool USE_SLAB>
+template <bool USE_SLAB, int NQ>
 __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__restrict__ tw,
 	const mifsk_demod_io &io, uint32_t slab_cap, uint32_t lat_frames, uint32_t lat_round,
 	uint32_t lat_mode, uint32_t base0, StreamLds *lds )
@@ -693,7 +799,9 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 		// (bad != 0 <=> n < K.)  With a search step of one sample a "refine"
 		// is a flag and no search (minimodem.c:1357): the cursor stays on the
 		// lattice and the batch in flight stays good -- 12000 baud lives there
-		if ( bad != 0ULL && cfg.try_step[1] > 1u )
+		// (where this wave can run the rescan alone the batch is dropped
+		// later, and only if the rescan moves the cursor off the lattice)
+		if ( NQ == 0 && bad != 0ULL && cfg.try_step[1] > 1u )
 		    ctx.give_up();
 		if ( n < K ) {			// the lattice broke here: remember how long it held
 		    ctx.spec = ctx.run < ctx.spec_floor ? ctx.spec_floor
@@ -843,7 +951,14 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 	    // `carrier` is already set: an acquiring frame is re-searched with
 	    // the data string over the no-carrier range (minimodem.c:1378)
 	    const uint32_t t_s2 = MIFSK_CLOCK();
-	    ScanResult s2 = ctx.scan(base, ci ? zf1 : zf0, try_first, INFINITY, 0u);
+	    ScanResult s2;
+	    bool alone = false;
+	    if constexpr ( NQ > 0 ) {
+		if ( ci && ctx.hit_base == base )
+		    alone = ctx.template solo_fine<NQ>(base, zf1, try_first, sr, s2);
+	    }
+	    if ( !alone )
+		s2 = ctx.scan(base, ci ? zf1 : zf0, try_first, INFINITY, 0u);
 	    cyc_s2 += MIFSK_CLOCK() - t_s2;
 	    flags |= MIFSK_FRAME_REFINED;
 	    n_refine++;
@@ -901,6 +1016,7 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 	    if ( ctx.pause ) {
 		ctx.pause--;			// the lattice kept missing: plain searches for a while
 	    } else if ( !cached && !( ctx.inflight && ctx.inflight_anchor == p ) ) {
+		ctx.give_up();			// (a batch left running by a rescan that moved the cursor)
 		if ( ctx.cold >= 4u ) {
 		    ctx.cold = 0;
 		    ctx.pause = 32;
@@ -1301,7 +1417,7 @@ void demod_kernel( const DevCfg *__restrict__ cfgp, const double *__restrict__ t
 	// the serial chain is the critical path of the workgroup: let it win
 	// issue arbitration against the (throughput-bound) worker waves
 	__builtin_amdgcn_s_setprio(3);
-	master_loop<USE_SLAB>(cfg, tw, io, slab_cap, lat_frames * lat_rounds, lat_frames, lat_mode, base0, lds);
+	master_loop<USE_SLAB, NQ>(cfg, tw, io, slab_cap, lat_frames * lat_rounds, lat_frames, lat_mode, base0, lds);
     } else {
 	worker_main<USE_SLAB, NQ>(cfgp, tw, lds, io.d_samples + (size_t)blockIdx.x * io.stream_stride,
 			      n_own, slab_cap, lat_frames, region_floats, region_cap, lat_mode, safe_limit,
