@@ -367,7 +367,9 @@ extern "C" int mifsk_find_frame_batch( mifsk_ctx *ctx, const mifsk_rx_config *cf
 // engine's master / worker pipeline overlaps the two and wins at every
 // batch size measured (0.32 vs 0.52 ms at 512 streams, 0.50 vs 0.59 at
 // 1024, 1.64 vs 2.19 at 4096); at 12000 baud (4 samples per bit) the
-// wavefront engine is 4 x faster.  Identical results either way.
+// wavefront engine is 4 x faster.  With longer windows and a clean signal it
+// still wins (tools/gpu/eng50.py, 2048 streams: 50 baud 3.0 vs 4.4 ms, 150 baud
+// 1.3 vs 4.1 ms).  Identical results either way.
 static bool use_workgroup_engine( const mifsk_rx_config *cfg, const DevCfg &d, unsigned flags )
 {
     const bool plain = !( flags & MIFSK_IO_RING_EXACT ) && !( cfg->auto_carrier_threshold > 0.0f );

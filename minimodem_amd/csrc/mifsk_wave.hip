@@ -1207,6 +1207,8 @@ bool plan_for( const DevCfg &cfg, const WaveHostArgs &ha, int sv, size_t budget,
     uint32_t slab_cap = ( reach + 4u + 3u ) & ~3u;
     size_t scan_floats = skewed_floats(slab_cap);
     const size_t region_floats = g.lat_mode == LAT_LINEAR ? round_floats + 16u : 0u;
+    if ( want_tile )
+	scan_floats = 0;		// the tile instead of a slab
 
     for (;;) {
 	// a SCAN chunk scores mags_cap / n_bits candidates at once: room for a
@@ -1272,7 +1274,12 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
 	force_sv = std::atoi(e);
     Plan plan;
     bool ok = false;
-    for ( uint32_t wpc = want; wpc >= 4u && !ok; wpc -= ( wpc > 8u ? 4u : ( wpc > 4u ? 2u : 1u ) ) ) {
+    // Long windows are better read through the tile at two waves per SIMD than
+    // from a slab that leaves one wave per SIMD (tools/ubench/longwin.hip: 17 ms
+    // against 45): a slab only while it fits 8 waves per CU then
+    const bool tile_ok = !ha.ring_exact && cfg.bit_nsamples >= 4u * TILE_K && force_sv != 4;
+    const uint32_t wmin = tile_ok ? 8u : 4u;
+    for ( uint32_t wpc = want; wpc >= wmin && !ok; wpc -= ( wpc > 8u ? 4u : ( wpc > 4u ? 2u : 1u ) ) ) {
 	const size_t budget = ( kLdsPerCu / wpc ) & ~(size_t)255;
 	// The wide-staging instantiation is compiled for two waves per SIMD (256
 	// VGPRs): worth it where rounds are staged through LDS (linear LATTICE) or

@@ -229,6 +229,41 @@ def test_random_batch_with_noise_matches_oracle(gpu, mode, variant):
     assert total > 10 * nwords
 
 
+@pytest.mark.parametrize("mode,kw", [("rtty", {}), ("rtty", dict(sample_rate=44100)), ("50", {}), ("30", {}),
+                                     ("20", {}), ("rtty", dict(sample_rate=96000))],
+                         ids=["B1056", "B970", "B960", "B1600", "B2400", "B2112"])
+def test_long_windows_through_the_tile(gpu, mode, kw):
+    """Bit windows too long for a search's span to sit in LDS are read from global memory
+    through the 64-sample tile (wave engine, demod_wave_kernel<10, -1>): bit lengths that are
+    a whole number of steps (960, 1600), that end in a short step (1056, 2112, 2400) and in a
+    short group (970), with noise, ragged ends and a stream that ends inside a window."""
+    M, torch, ctx = gpu
+    cfg = M.rx_config(mode, **kw)
+    ocfg = O.oracle_config(mode, **kw)
+    assert "demod_wave_kernel<10, -1>" in M.demod_plan(ctx, cfg, 8, engine="wave")["kernel"]
+    rng = np.random.default_rng(77)
+    five = cfg.n_data_bits == 5
+    streams = []
+    for i in range(6):
+        words = rng.integers(0 if five else 32, 32 if five else 127, size=5 + i, dtype=np.uint8)
+        x = M.synthesize(cfg, words, leading_silence=int(rng.integers(0, 200)),
+                         amplitude=float(rng.uniform(0.3, 1.0)))
+        sigma = [0.0, 0.05, 0.2][i % 3]
+        if sigma:
+            x = (x + rng.normal(0, sigma, x.shape)).astype(np.float32)
+        if i == 4:
+            x = x[: len(x) - int(cfg.bit_nsamples) // 3]      # ends inside a bit window
+        streams.append(x)
+    streams.append(rng.normal(0, 0.3, 6 * int(ocfg.expect_nsamples)).astype(np.float32))
+    res = run_gpu_streams(M, torch, ctx, cfg, streams, engine="wave", ring=False)
+    total = 0
+    for i, s in enumerate(streams):
+        ref = O.oracle_rx_stream(ocfg, s)
+        assert_stream_equal(res, i, ref, mode)
+        total += len(ref["frames"])
+    assert total > 20
+
+
 @pytest.mark.parametrize("mode,tones", [
     ("300", [(1270, 1070), (1570, 1370), (2025, 1825), (980, 780), (3000, 2800)]),
     ("1200", [(1200, 2200), (1500, 2300), (2000, 2800), (1000, 1800), (2600, 3400)]),
