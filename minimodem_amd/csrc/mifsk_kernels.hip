@@ -720,6 +720,9 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
     uint32_t n_iter = 0, n_bulk = 0, n_refine = 0;
     uint32_t cyc_bulk = 0, cyc_general = 0, cyc_restart = 0, cyc_s1 = 0, cyc_s2 = 0, cyc_dpp = 0;
     const uint32_t t_start = MIFSK_CLOCK();
+#ifdef MIFSK_PROFILE
+    const uint32_t t_wall0 = (uint32_t)wall_clock64();
+#endif
 
     const ZigZag zc0(cfg.try_first[0], cfg.try_max[0], cfg.try_step[0]);
     const ZigZag zc1(cfg.try_first[1], cfg.try_max[1], cfg.try_step[1]);
@@ -1075,6 +1078,12 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 	    c[19] = cyc_s2;
 	    c[20] = cyc_dpp;
 	    c[21] = ctx.cyc_scan_wait;
+#ifdef MIFSK_PROFILE
+	    // when this stream started and ended on the chip-wide 100 MHz clock
+	    c[23] = ( wall_clock64() & 0xFFFFFFFFull ) | ( (uint64_t)t_wall0 << 32 );
+	    // HW_REG_XCC_ID (gfx940+)
+	    c[22] = (uint64_t)( __builtin_amdgcn_s_getreg(( 3 << 11 ) | 20) & 15 ) << 32;
+#endif
 	}
 	ctx.next_cmd()->op = CMD_EXIT;
     }

@@ -683,6 +683,9 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
     uint32_t n_iter = 0, n_bulk = 0, n_refine = 0, n_detect = 0;
     uint32_t cyc_bulk = 0, cyc_general = 0;
     const uint32_t t_start = MIFSK_WCLOCK();
+#ifdef MIFSK_PROFILE
+    const uint32_t t_wall0 = (uint32_t)wall_clock64();
+#endif
 
     const ZigZag zc0(cfg.try_first[0], cfg.try_max[0], cfg.try_step[0]);
     const ZigZag zc1(cfg.try_first[1], cfg.try_max[1], cfg.try_step[1]);
@@ -1119,6 +1122,12 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 	    c[18] = ctx.cyc_s_corr;
 	    c[19] = ctx.cyc_s_conf;
 	    c[22] = n_detect;
+#ifdef MIFSK_PROFILE
+	    // when this stream started and ended on the chip-wide 100 MHz clock
+	    c[23] = ( wall_clock64() & 0xFFFFFFFFull ) | ( (uint64_t)t_wall0 << 32 );
+	    // HW_REG_XCC_ID (gfx940+)
+	    c[22] |= (uint64_t)( __builtin_amdgcn_s_getreg(( 3 << 11 ) | 20) & 15 ) << 32;
+#endif
 	}
     }
 }

@@ -52,6 +52,26 @@ def main():
         col = c[:, idx]
         if col.max() > 0:
             print("%-16s mean %12.1f  min %12.0f  max %12.0f" % (name, col.mean(), col.min(), col.max()))
+    raw = out["counters"].cpu().numpy().view(np.uint64)
+    if (raw[:, 23] != 0).any():
+        # where the streams sit inside the launch: start and end of each on the chip-wide
+        # 100 MHz clock (s_memrealtime), its XCD from HW_REG_XCC_ID
+        end = (raw[:, 23] & np.uint64(0xFFFFFFFF)).astype(np.float64) * 1e-2      # microseconds
+        start = (raw[:, 23] >> np.uint64(32)).astype(np.float64) * 1e-2
+        end = np.where(end < start, end + 2.0 ** 32 * 1e-2, end)                    # (32-bit wrap)
+        xcc = (raw[:, 22] >> np.uint64(32)).astype(np.int64)
+        t0 = start.min()
+        print("streams per XCD:", np.bincount(xcc, minlength=8).tolist())
+        print("stream starts %.1f ... %.1f us after the first, ends %.1f ... %.1f us (mean %.1f); events: %.1f us"
+              % ((start - t0).min(), (start - t0).max(), (end - t0).min(), (end - t0).max(), (end - t0).mean(),
+                 float(np.median(ts)) * 1e3))
+        dur = end - start
+        print("stream duration min %.1f mean %.1f max %.1f us; resident streams on average %.0f"
+              % (dur.min(), dur.mean(), dur.max(), dur.sum() / (end.max() - t0)))
+        for xcd in range(8):
+            m = xcc == xcd
+            if m.any():
+                print("  XCD %d: last end %.1f us, mean duration %.1f us" % (xcd, (end[m] - t0).max(), dur[m].mean()))
     tot = c[:, 8].mean()
     if tot > 0:
         for idx in (9, 10, 11, 12, 13, 14, 16):

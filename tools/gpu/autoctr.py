@@ -25,4 +25,5 @@ for auto in (0.0, 0.001):
         col = c[:, idx]
         if col.max() > 0:
             print("  %-16s mean %12.1f  min %12.0f  max %12.0f" % (name, col.mean(), col.min(), col.max()))
-    print("  n_detect (c[22]) mean %.1f max %.0f" % (c[:, 22].mean(), c[:, 22].max()))
+    nd = out["counters"].cpu().numpy().view(np.uint64)[:, 22] & np.uint64(0xFFFFFFFF)
+    print("  n_detect mean %.1f max %.0f" % (nd.mean(), nd.max()))
