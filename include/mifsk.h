@@ -249,7 +249,7 @@ typedef struct mifsk_demod_io {
  * reference's buffer is kept cell for cell in device memory and every frame
  * goes through the general path: exact, and several times slower. */
 #define MIFSK_IO_RING_EXACT	1u
-/* Run the receive loop with one 256-thread workgroup per stream (master wave +
+/* Run the receive loop with one workgroup per stream (192 or 256 threads: master wave +
  * worker waves; the round-1 kernel) instead of one wavefront per stream.
  * Flat addressing only; --auto-carrier looks for the tone once per stream. */
 #define MIFSK_IO_ENGINE_WORKGROUP 2u

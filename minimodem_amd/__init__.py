@@ -135,7 +135,7 @@ def demod_batch(ctx, cfg, samples, nsamples=None, want=("bytes", "episodes"),
     reuse its buffers (nothing is allocated inside the timed region then).
     ring_exact: MIFSK_IO_RING_EXACT (the reference's stale-cell buffer semantics).
     engine: None (the library chooses), "wave" (one wavefront per stream,
-    MIFSK_IO_ENGINE_WAVE) or "workgroup" (one 256-thread workgroup per stream,
+    MIFSK_IO_ENGINE_WAVE) or "workgroup" (one workgroup of a master and 2-3 worker waves per stream,
     MIFSK_IO_ENGINE_WORKGROUP); force_engine=True makes None mean "wave".
     """
     torch = _torch()

@@ -506,7 +506,9 @@ extern "C" int mifsk_demod_plan( mifsk_ctx *ctx, const mifsk_rx_config *cfg, int
     out->workgroup_size = li.workgroup_size;
     out->lds_bytes_per_workgroup = li.lds_bytes;
     const unsigned by_lds = li.lds_bytes ? (unsigned)( 160u * 1024u / li.lds_bytes ) : 32u;
-    const unsigned by_waves = 32u * 64u / ( li.workgroup_size ? li.workgroup_size : 64u );
+    // (waves per SIMD the instantiation's VGPR budget allows x 4 SIMDs)
+    const unsigned by_waves = ( li.waves_per_simd ? li.waves_per_simd : 8u ) * 4u * 64u
+			    / ( li.workgroup_size ? li.workgroup_size : 64u );
     out->workgroups_per_cu = by_lds < by_waves ? by_lds : by_waves;
     out->lattice_mode = li.lattice_mode;
     out->frames_per_block = li.frames_per_block;

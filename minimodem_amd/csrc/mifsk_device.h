@@ -74,6 +74,7 @@ struct LaunchInfo {
     uint32_t	lds_bytes;		// dynamic LDS per workgroup
     uint32_t	lattice_mode;		// LAT_*
     uint32_t	frames_per_block;	// LATTICE frames scored at once, at most
+    uint32_t	waves_per_simd;		// what the instantiation is compiled for (its VGPR budget)
 };
 
 int launch_demod_batch( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_tw,

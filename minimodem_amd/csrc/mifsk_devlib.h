@@ -16,7 +16,6 @@
 
 namespace mifsk {
 
-constexpr int BLOCK = 256;	// threads per stream workgroup (4 waves)
 constexpr int P_CAP = 64;	// candidate positions per batch (= one wave of lanes)
 constexpr int W_CAP = 448;	// bit windows per batch (LDS scratch)
 

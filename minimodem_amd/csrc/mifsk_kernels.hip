@@ -30,6 +30,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 
 #include "mifsk_device.h"
 #include "mifsk_devmath.h"
@@ -171,8 +172,12 @@ void find_frame_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 __device__ __forceinline__ void lds_barrier();
 __device__ __forceinline__ float lane_bcast( float v, uint32_t src );
 
-constexpr int NWORKERS = 3;
-constexpr int LAT_LANES = NWORKERS * 64;	// bit windows per lattice batch
+// A stream's workgroup is a master wave and NW worker waves (blockDim.x = 64 (NW +
+// 1)): three workers, or two in the Bell-202 instantiation -- configs[1] measured
+// 0.448 ms with two (rounds of 12 frames, batches of 24, 142 VGPRs at three waves
+// per SIMD: nothing spilled), 0.474-0.486 with three (19 / 38, 128 VGPRs, 12
+// spilled), 0.52 with one; the long-window linear modes are 10-15 % faster with
+// three (tools/gpu/eng50.py).
 
 struct StreamLds {
     float2	mags[2][W_CAP];	// [buffer][window]: (mark, space) magnitudes
@@ -216,21 +221,21 @@ __device__ __forceinline__ void par_stage( const DevCfg &cfg, StreamLds *lds, co
     const uint32_t org4 = row_org & ~3u;
     const uint32_t head = row_org - org4;		// 0..3 samples before row 0: dropped
     const uint32_t nvec = ( nstage + head + 3 ) >> 2;
-    for ( uint32_t v0 = 0; v0 < nvec; v0 += BLOCK * STAGE_VEC ) {
+    for ( uint32_t v0 = 0; v0 < nvec; v0 += blockDim.x * STAGE_VEC ) {
 	float4 buf[STAGE_VEC];
 	// all loads of the round in flight before the first LDS write; vector
 	// groups wholly past the end are neither loaded nor stored (uniform tests:
 	// a refinement with the carrier held stages a few hundred samples only)
 #pragma unroll
 	for ( int i = 0; i < STAGE_VEC; i++ ) {
-	    const uint32_t v = v0 + i * BLOCK + threadIdx.x;
-	    if ( v0 + i * BLOCK < nvec )
+	    const uint32_t v = v0 + i * blockDim.x + threadIdx.x;
+	    if ( v0 + i * blockDim.x < nvec )
 		buf[i] = load4_raw(x, org4 + ( v << 2 ), N);
 	}
 #pragma unroll
 	for ( int i = 0; i < STAGE_VEC; i++ ) {
-	    const uint32_t v = v0 + i * BLOCK + threadIdx.x;
-	    if ( v0 + i * BLOCK < nvec && v < nvec )
+	    const uint32_t v = v0 + i * blockDim.x + threadIdx.x;
+	    if ( v0 + i * blockDim.x < nvec && v < nvec )
 		store4_skewed(cfg, lds->slab, slab_cap, v << 2, head, buf[i], org4 + ( v << 2 ), N);
 	}
     }
@@ -244,7 +249,7 @@ __device__ __forceinline__ void par_correlate( const DevCfg &cfg, const double *
     const uint32_t n_bits = cfg.n_bits;
     const uint32_t B = cfg.bit_nsamples;
     const uint32_t nwin = nq * n_bits;
-    for ( uint32_t w0 = 0; w0 < nwin; w0 += BLOCK ) {
+    for ( uint32_t w0 = 0; w0 < nwin; w0 += blockDim.x ) {
 	const uint32_t w = w0 + threadIdx.x;
 	if ( w0 + ( threadIdx.x & ~63u ) >= nwin )
 	    continue;			// nothing for this wave in this pass (a refinement has ~90 windows)
@@ -1392,8 +1397,8 @@ __device__ __forceinline__ void worker_main( const DevCfg *__restrict__ cfgp,
 #endif
 }
 
-template <bool USE_SLAB, int NQ>
-__global__ __launch_bounds__(BLOCK, 4)
+template <bool USE_SLAB, int NQ, int NW>
+__global__ __launch_bounds__(64 * ( NW + 1 ), NW == 2 ? 3 : 4)
 void demod_kernel( const DevCfg *__restrict__ cfgp, const double *__restrict__ tw,
 	mifsk_demod_io io, uint32_t slab_cap, uint32_t lat_frames, uint32_t lat_rounds,
 	uint32_t region_floats, uint32_t region_cap, uint32_t lat_mode )
@@ -1484,12 +1489,16 @@ int launch_find_frame_batch( const DevCfg &cfg, const DevCfg *d_cfg, const doubl
 static constexpr size_t kLdsHeader = offsetof(StreamLds, slab);
 static constexpr size_t kLdsPerCu = 160 * 1024;
 
-int launch_demod_batch( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_tw,
-	const mifsk_demod_io &io, void *stream, LaunchInfo *plan_only )
+// `nworkers` = 2 asks for the Bell-202 instantiation; kNotBell202 if the
+// configuration does not end up there (the caller then plans with three)
+static constexpr int kNotBell202 = -100000;
+
+static int launch_with_workers( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_tw,
+	const mifsk_demod_io &io, void *stream, LaunchInfo *plan_only, const uint32_t nworkers )
 {
-    if ( io.nstreams <= 0 && !plan_only )
-	return 0;
     const uint32_t B = cfg.bit_nsamples;
+    const uint32_t lat_lanes = nworkers * 64u;	// bit windows per lattice round
+    const uint32_t block = 64u * ( nworkers + 1u );
     // samples one search must see at once
     const uint32_t reach = ( cfg.try_max[0] > cfg.try_max[1] ? cfg.try_max[0] : cfg.try_max[1] )
 			 + cfg.last_reach + 8;
@@ -1504,8 +1513,8 @@ int launch_demod_batch( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_
     // a private LDS region (fastest; needs bit length, offsets and frame step
     // in multiples of 4 samples and the span to fit ten 16-byte loads per
     // lane); otherwise DIRECT workers stream each window from global memory.
-    const uint32_t frames_max = cfg.lat_grid ? ( LAT_LANES - 1u ) / ( cfg.n_bits - 1u )
-					     : LAT_LANES / cfg.n_bits;
+    const uint32_t frames_max = cfg.lat_grid ? ( lat_lanes - 1u ) / ( cfg.n_bits - 1u )
+					     : lat_lanes / cfg.n_bits;
     uint32_t lat_frames = frames_max > P_CAP ? P_CAP : frames_max;
     auto wins_in = [&]( uint32_t frames ) -> uint32_t {
 	return cfg.lat_grid ? frames * ( cfg.n_bits - 1u ) + 1u : frames * cfg.n_bits;
@@ -1541,8 +1550,8 @@ int launch_demod_batch( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_
 	region_cap = ( span + 3 ) & ~3u;
 	region_floats = floats_for(region_cap);
 	if ( region_cap <= 64u * STAGE_VEC * 4u
-		&& kLdsHeader + NWORKERS * region_floats * 4 <= budget_small
-		&& NWORKERS * region_floats >= floats_for(reach + 4) )
+		&& kLdsHeader + nworkers * region_floats * 4 <= budget_small
+		&& nworkers * region_floats >= floats_for(reach + 4) )
 	    lat_mode = LAT_LINEAR;
     }
 
@@ -1552,6 +1561,8 @@ int launch_demod_batch( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_
     uint32_t lat_rounds = 1;
     if ( lat_frames ) {
 	lat_rounds = 2;
+	if ( const char *e = std::getenv("MIFSK_LAT_ROUNDS") )	// experiments only
+	    lat_rounds = (uint32_t)std::atoi(e) < 1u ? 1u : (uint32_t)std::atoi(e);
 	while ( lat_rounds > 1 && ( lat_frames * lat_rounds > P_CAP
 				    || wins_in(lat_frames) * lat_rounds > W_CAP ) )
 	    lat_rounds--;
@@ -1561,7 +1572,7 @@ int launch_demod_batch( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_
     size_t slab_floats = 0;
     bool use_slab = true;
     if ( lat_mode == LAT_LINEAR ) {
-	slab_floats = NWORKERS * region_floats;
+	slab_floats = nworkers * region_floats;
 	// samples the whole slab holds in SCAN mode
 	size_t ns = slab_floats * B / ( B + cfg.skew );
 	ns = ns > 16 ? ns - 16 : 0;
@@ -1582,38 +1593,53 @@ int launch_demod_batch( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_
     }
 
     hipStream_t st = (hipStream_t)stream;
+    const bool bell202 = nworkers == 2u && use_slab && lat_mode == LAT_LINEAR && B == 40u;
+    if ( nworkers == 2u && !bell202 )
+	return kNotBell202;
     if ( plan_only ) {
-	const bool b202 = use_slab && lat_mode == LAT_LINEAR && B == 40u;
-	plan_only->kernel = !use_slab ? "mifsk::demod_kernel<false, 0>"
-			  : b202 ? "mifsk::demod_kernel<true, 10>" : "mifsk::demod_kernel<true, 0>";
-	plan_only->workgroup_size = BLOCK;
+	plan_only->kernel = !use_slab ? "mifsk::demod_kernel<false, 0, 3>"
+			  : bell202 ? "mifsk::demod_kernel<true, 10, 2>" : "mifsk::demod_kernel<true, 0, 3>";
+	plan_only->workgroup_size = block;
 	plan_only->lds_bytes = (uint32_t)( use_slab ? kLdsHeader + slab_floats * 4 : kLdsHeader + 16 );
 	plan_only->lattice_mode = lat_mode;
 	plan_only->frames_per_block = lat_frames * lat_rounds;
+	plan_only->waves_per_simd = bell202 ? 3 : 4;
 	return 0;
     }
     if ( use_slab ) {
 	const size_t lds_bytes = kLdsHeader + slab_floats * 4;
-	const bool bell202 = lat_mode == LAT_LINEAR && B == 40u;
 	hipError_t e = hipFuncSetAttribute(
-		bell202 ? reinterpret_cast<const void *>(&demod_kernel<true, 10>)
-			: reinterpret_cast<const void *>(&demod_kernel<true, 0>),
+		bell202 ? reinterpret_cast<const void *>(&demod_kernel<true, 10, 2>)
+			: reinterpret_cast<const void *>(&demod_kernel<true, 0, 3>),
 		hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 	if ( e != hipSuccess )
 	    return hip_rc(e);
 	if ( bell202 )
-	    hipLaunchKernelGGL((demod_kernel<true, 10>), dim3((unsigned)io.nstreams), dim3(BLOCK),
+	    hipLaunchKernelGGL((demod_kernel<true, 10, 2>), dim3((unsigned)io.nstreams), dim3(block),
 			       lds_bytes, st, d_cfg, d_tw, io, slab_cap, lat_frames, lat_rounds,
 			       (uint32_t)region_floats, region_cap, lat_mode);
 	else
-	    hipLaunchKernelGGL((demod_kernel<true, 0>), dim3((unsigned)io.nstreams), dim3(BLOCK),
+	    hipLaunchKernelGGL((demod_kernel<true, 0, 3>), dim3((unsigned)io.nstreams), dim3(block),
 			       lds_bytes, st, d_cfg, d_tw, io, slab_cap, lat_frames, lat_rounds,
 			       (uint32_t)region_floats, region_cap, lat_mode);
     } else {
-	hipLaunchKernelGGL((demod_kernel<false, 0>), dim3((unsigned)io.nstreams), dim3(BLOCK),
+	hipLaunchKernelGGL((demod_kernel<false, 0, 3>), dim3((unsigned)io.nstreams), dim3(block),
 			   kLdsHeader + 16, st, d_cfg, d_tw, io, 0u, 0u, 1u, 0u, 0u, (uint32_t)LAT_NONE);
     }
     return hip_rc(hipGetLastError());
+}
+
+int launch_demod_batch( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_tw,
+	const mifsk_demod_io &io, void *stream, LaunchInfo *plan_only )
+{
+    if ( io.nstreams <= 0 && !plan_only )
+	return 0;
+    if ( cfg.lat_linear && cfg.bit_nsamples == 40u ) {
+	const int rc = launch_with_workers(cfg, d_cfg, d_tw, io, stream, plan_only, 2u);
+	if ( rc != kNotBell202 )
+	    return rc;
+    }
+    return launch_with_workers(cfg, d_cfg, d_tw, io, stream, plan_only, 3u);
 }
 
 int launch_detect_carrier( const float *d_samples, unsigned nsamples,

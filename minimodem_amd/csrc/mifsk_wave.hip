@@ -1347,6 +1347,7 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
 	plan_only->lds_bytes = (uint32_t)plan.lds_bytes;
 	plan_only->lattice_mode = g.lat_mode;
 	plan_only->frames_per_block = g.lat_mode != LAT_NONE ? g.lat_fmax : 0u;
+	plan_only->waves_per_simd = plan.sv == 10 ? 2u : 4u;
 	return 0;
     }
     hipStream_t st = (hipStream_t)stream;

@@ -409,7 +409,7 @@ def test_demod_plan_reports_engine_and_lds(gpu):
     (rocprofv3 does not report dynamic LDS; this is the occupancy evidence)."""
     M, torch, ctx = gpu
     p = M.demod_plan(ctx, M.rx_config("1200"), 1024)
-    assert p["engine"] == "workgroup" and p["workgroup_size"] == 256 and "demod_kernel<true, 10>" in p["kernel"]
+    assert p["engine"] == "workgroup" and p["workgroup_size"] == 192 and "demod_kernel<true, 10, 2>" in p["kernel"]
     assert p["lds_bytes_per_workgroup"] <= 40960 and p["workgroups_per_cu"] == 4
     p = M.demod_plan(ctx, M.rx_config("1200"), 1024, engine="wave")
     assert p["engine"] == "wave" and "demod_wave_kernel<10, 10>" in p["kernel"] and p["lattice_mode"] == 1
