@@ -1508,7 +1508,7 @@ static int launch_with_workers( const DevCfg &cfg, const DevCfg *d_cfg, const do
     // LDS budget: 4 workgroups per CU when the stream count can use them
     const size_t budget_small = kLdsPerCu / 4 - 64;
 
-    // LATTICE geometry.  A round is as many frames as fill the 192 worker lanes
+    // LATTICE geometry.  A round is as many frames as fill the worker lanes (64 per worker)
     // with distinct bit windows.  LINEAR workers stage their 64 windows' span in
     // a private LDS region (fastest; needs bit length, offsets and frame step
     // in multiples of 4 samples and the span to fit ten 16-byte loads per
