@@ -22,6 +22,7 @@
 namespace mifsk {
 
 constexpr int TX_BLOCK = 256;		// threads per stream; also tones per chunk
+constexpr int TX_QUOT = 1024;		// longest bit (samples) with a quotient table
 
 struct TxArgs {
     const uint8_t	*d_words;	size_t words_stride;
@@ -87,13 +88,24 @@ __device__ Tone tone_at( const TxArgs &a, const uint8_t *words, uint32_t nwords,
     return t;
 }
 
+// One workgroup per stream, chunks of TX_BLOCK tones.  Wave 0 is the phase
+// accumulator -- a sequential f32 recurrence over the tones
+// (simple-tone-generator.c:164-166), run by its lane 0 one chunk ahead -- and
+// waves 1-3 write the samples of the chunk before.  What the recurrence adds per
+// tone and the tone's samples per wave (the two divisions of :117,164) are
+// computed one tone per thread when the chunk is fetched.
 __global__ __launch_bounds__(TX_BLOCK)
 void tx_synth_kernel( TxArgs a )
 {
-    __shared__ float s_freq[TX_BLOCK];
-    __shared__ float s_phase[TX_BLOCK];		// cphase at the start of each tone
-    __shared__ uint32_t s_off[TX_BLOCK + 1];	// first sample of each tone within the chunk
-    __shared__ float s_carry;
+    __shared__ float s_wn[2][TX_BLOCK];		// samples per wave of each tone (:117)
+    __shared__ __attribute__((aligned(16))) float s_dq[2][TX_BLOCK];	// what the tone adds to the phase (:164)
+    __shared__ __attribute__((aligned(16))) float s_phase[2][TX_BLOCK];	// cphase at the start of each tone
+    __shared__ __attribute__((aligned(16))) uint32_t s_n[2][TX_BLOCK];	// samples of each tone
+    __shared__ __attribute__((aligned(16))) uint32_t s_off[2][TX_BLOCK + 4];	// first sample of each tone within the chunk
+    // (float)i / wave_nsamples for the two tones, where every tone is as long as a
+    // data bit and short enough: a sample then looks its quotient up instead of
+    // dividing (the same division, made once per i)
+    __shared__ float s_quot[2][TX_QUOT];
 
     const uint32_t s = blockIdx.x;
     const uint8_t *words = a.d_words + (size_t)s * a.words_stride;
@@ -106,62 +118,150 @@ void tx_synth_kernel( TxArgs a )
     for ( size_t j = threadIdx.x; j < lead && j < cap; j += TX_BLOCK )
 	out[j] = 0.0f;
     size_t pos = lead;
-    if ( threadIdx.x == 0 )
-	s_carry = 0.0f;
-    __syncthreads();
 
     const uint32_t per_frame = ( a.start_nsamples ? 1u : 0u ) + a.ndata + ( a.stop_nsamples ? 1u : 0u );
     const uint32_t ntones = nwords ? (uint32_t)a.leader + ( (uint32_t)a.nsync + nwords ) * per_frame + 2u
 				   : 0u;
-    for ( uint32_t q0 = 0; q0 < ntones; q0 += TX_BLOCK ) {
-	const uint32_t q = q0 + threadIdx.x;
-	const Tone t = q < ntones ? tone_at(a, words, nwords, q) : Tone{ 0.0f, 0u };
-	s_freq[threadIdx.x] = t.freq;
-	s_off[threadIdx.x + 1] = t.n;
-	__syncthreads();
-	if ( threadIdx.x == 0 ) {
-	    // the phase accumulator is a sequential f32 recurrence over the tones
-	    // (simple-tone-generator.c:164-166); lengths -> prefix offsets
-	    float cphase = s_carry;
-	    uint32_t off = 0;
-	    s_off[0] = 0;
-	    for ( int k = 0; k < TX_BLOCK; k++ ) {
-		const uint32_t n = s_off[k + 1];
-		s_phase[k] = cphase;
-		if ( n ) {
-		    const float wave_nsamples = (float)a.sample_rate / s_freq[k];
-		    cphase = cphase + (float)n / wave_nsamples;
-		    cphase = cphase - truncf(cphase);		// fmodf(x, 1.0f), x >= 0: exact
-		}
-		off += n;
-		s_off[k + 1] = off;
-	    }
-	    s_carry = cphase;
+    const uint32_t nchunks = ( ntones + TX_BLOCK - 1u ) / TX_BLOCK;
+    // every tone of the stream as long as a data bit (no 1.5 stop bits ...): the
+    // tone of a sample is a division by a constant instead of a search
+    const bool uniform = ( !a.start_nsamples || a.start_nsamples == a.bit_nsamples )
+		      && ( !a.stop_nsamples || a.stop_nsamples == a.bit_nsamples ) && a.bit_nsamples > 1u;
+    const uint32_t bit_magic = uniform ? (uint32_t)( 0x100000000ULL / a.bit_nsamples ) : 0u;
+    const bool pow2 = a.table_len && ( a.table_len & ( a.table_len - 1u ) ) == 0u;
+    float cphase = 0.0f;			// (lane 0 of wave 0)
+    const bool quot = uniform && a.bit_nsamples <= (uint32_t)TX_QUOT;
+    const bool vec4 = quot && a.table_len && ( a.bit_nsamples & 3u ) == 0u;
+    if ( quot ) {
+	const float wn_mark = (float)a.sample_rate / a.mark, wn_space = (float)a.sample_rate / a.space;
+	for ( uint32_t i = threadIdx.x; i < a.bit_nsamples; i += TX_BLOCK ) {
+	    s_quot[0][i] = (float)i / wn_mark;
+	    s_quot[1][i] = (float)i / wn_space;
 	}
+    }
+
+    auto fetch = [&]( uint32_t c, uint32_t b ) {
+	const uint32_t q = c * TX_BLOCK + threadIdx.x;
+	const Tone t = q < ntones ? tone_at(a, words, nwords, q) : Tone{ 0.0f, 0u };
+	const float wn = t.n ? (float)a.sample_rate / t.freq : 1.0f;
+	// (with the quotient table: which of the two tones, as a float)
+	s_wn[b][threadIdx.x] = quot ? ( t.freq == a.mark ? 0.0f : 1.0f ) : wn;
+	s_dq[b][threadIdx.x] = t.n ? (float)t.n / wn : 0.0f;
+	s_n[b][threadIdx.x] = t.n;
+    };
+    // lengths -> prefix offsets, phases.  Four tones per step: the LDS reads do not
+    // sit inside the dependent chain.  (A tone of no samples -- past the end --
+    // adds 0.0f to a phase in [0, 1): nothing.)
+    auto scan = [&]( uint32_t b ) {
+	uint32_t off = 0;
+	for ( int k = 0; k < TX_BLOCK; k += 4 ) {
+	    const float4 d = *reinterpret_cast<const float4 *>(&s_dq[b][k]);
+	    const uint4 n = *reinterpret_cast<const uint4 *>(&s_n[b][k]);
+	    float4 ph;
+	    uint4 st;
+	    ph.x = cphase;  st.x = off;
+	    cphase = cphase + d.x;  cphase = cphase - truncf(cphase);	// fmodf(x, 1.0f), x >= 0: exact
+	    off += n.x;
+	    ph.y = cphase;  st.y = off;
+	    cphase = cphase + d.y;  cphase = cphase - truncf(cphase);
+	    off += n.y;
+	    ph.z = cphase;  st.z = off;
+	    cphase = cphase + d.z;  cphase = cphase - truncf(cphase);
+	    off += n.z;
+	    ph.w = cphase;  st.w = off;
+	    cphase = cphase + d.w;  cphase = cphase - truncf(cphase);
+	    off += n.w;
+	    *reinterpret_cast<float4 *>(&s_phase[b][k]) = ph;
+	    *reinterpret_cast<uint4 *>(&s_off[b][k]) = st;
+	}
+	s_off[b][TX_BLOCK] = off;
+    };
+
+    if ( nchunks ) {
+	fetch(0, 0);
 	__syncthreads();
-	const uint32_t total = s_off[TX_BLOCK];
-	for ( uint32_t j = threadIdx.x; j < total; j += TX_BLOCK ) {
-	    // tone of sample j: last k with s_off[k] <= j
-	    uint32_t lo = 0, hi = TX_BLOCK;
-	    while ( hi - lo > 1 ) {
-		const uint32_t mid = ( lo + hi ) >> 1;
-		if ( s_off[mid] <= j ) lo = mid; else hi = mid;
+	if ( threadIdx.x == 0 )
+	    scan(0);
+	__syncthreads();
+    }
+    for ( uint32_t c = 0; c < nchunks; c++ ) {
+	const uint32_t b = c & 1u;
+	if ( c + 1u < nchunks )
+	    fetch(c + 1u, b ^ 1u);
+	__syncthreads();
+	const uint32_t total = s_off[b][TX_BLOCK];
+	if ( threadIdx.x < 64u ) {
+	    if ( threadIdx.x == 0 && c + 1u < nchunks )
+		scan(b ^ 1u);
+	} else if ( vec4 ) {
+	    // four consecutive samples per thread: they share their tone (bits are
+	    // a multiple of four samples long), hence its offset, phase and table
+	    // row, and leave in one 16-byte store -- a third of the instructions
+	    for ( uint32_t j = 4u * ( threadIdx.x - 64u ); j < total; j += 4u * ( TX_BLOCK - 64u ) ) {
+		uint32_t lo = __umulhi(j, bit_magic);			// floor(j / B) or one less
+		if ( j - lo * a.bit_nsamples >= a.bit_nsamples )
+		    lo++;
+		const uint32_t i = j - s_off[b][lo];
+		const float *qrow = s_quot[s_wn[b][lo] != 0.0f] + i;
+		const float ph = s_phase[b][lo];
+		float v[4];
+#pragma unroll
+		for ( int u = 0; u < 4; u++ ) {
+		    const float turns = qrow[u] + ph;				// :117-118
+		    int ti = (int)( (float)a.table_len * turns + 0.5f );	// :120-121
+		    if ( pow2 )
+			ti &= (int)( a.table_len - 1u );			// (ti >= 0)
+		    else
+			ti %= (int)a.table_len;
+		    v[u] = a.as_s16 ? (float)a.tab_s[ti] / 32768.0f : a.tab_f[ti];
+		}
+		// (total is a multiple of four here: all four samples exist)
+		if ( pos + j + 3u < cap ) {
+		    typedef float float4_u __attribute__((ext_vector_type(4), aligned(4)));
+		    float4_u o; o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
+		    *reinterpret_cast<float4_u *>(out + pos + j) = o;
+		} else {
+#pragma unroll
+		    for ( int u = 0; u < 4; u++ )
+			if ( pos + j + (uint32_t)u < cap )
+			    out[pos + j + (uint32_t)u] = v[u];
+		}
 	    }
-	    const uint32_t i = j - s_off[lo];
-	    const float wave_nsamples = (float)a.sample_rate / s_freq[lo];
-	    const float turns = (float)i / wave_nsamples + s_phase[lo];	// :118
-	    float v;
-	    if ( a.table_len ) {
-		int ti = (int)( (float)a.table_len * turns + 0.5f );		// :120-121
-		ti %= (int)a.table_len;
-		v = a.as_s16 ? (float)a.tab_s[ti] / 32768.0f : a.tab_f[ti];
-	    } else {
-		const float rad = (float)M_PI * 2 * turns;			// :116,134,155
-		const float sn = mifsk_glibc_sinf(rad);
-		v = a.as_s16 ? (float)(short)lroundf(a.mag_s * sn) / 32768.0f : a.mag * sn;
+	} else {
+	    for ( uint32_t j = threadIdx.x - 64u; j < total; j += TX_BLOCK - 64u ) {
+		// tone of sample j: last k with s_off[k] <= j
+		uint32_t lo;
+		if ( uniform ) {
+		    lo = __umulhi(j, bit_magic);			// floor(j / B) or one less
+		    if ( j - lo * a.bit_nsamples >= a.bit_nsamples )
+			lo++;
+		} else {
+		    lo = 0;
+		    uint32_t hi = TX_BLOCK;
+		    while ( hi - lo > 1 ) {
+			const uint32_t mid = ( lo + hi ) >> 1;
+			if ( s_off[b][mid] <= j ) lo = mid; else hi = mid;
+		    }
+		}
+		const uint32_t i = j - s_off[b][lo];
+		const float w = s_wn[b][lo];
+		const float turns = ( quot ? s_quot[w != 0.0f][i] : (float)i / w ) + s_phase[b][lo];	// :117-118
+		float v;
+		if ( a.table_len ) {
+		    int ti = (int)( (float)a.table_len * turns + 0.5f );		// :120-121
+		    if ( pow2 )
+			ti &= (int)( a.table_len - 1u );		// (ti >= 0)
+		    else
+			ti %= (int)a.table_len;
+		    v = a.as_s16 ? (float)a.tab_s[ti] / 32768.0f : a.tab_f[ti];
+		} else {
+		    const float rad = (float)M_PI * 2 * turns;			// :116,134,155
+		    const float sn = mifsk_glibc_sinf(rad);
+		    v = a.as_s16 ? (float)(short)lroundf(a.mag_s * sn) / 32768.0f : a.mag * sn;
+		}
+		if ( pos + j < cap )
+		    out[pos + j] = v;
 	    }
-	    if ( pos + j < cap )
-		out[pos + j] = v;
 	}
 	pos += total;
 	__syncthreads();
