@@ -68,6 +68,12 @@ def main():
         dur = end - start
         print("stream duration min %.1f mean %.1f max %.1f us; resident streams on average %.0f"
               % (dur.min(), dur.mean(), dur.max(), dur.sum() / (end.max() - t0)))
+        refs = c[:, 4]
+        for lo_, hi_ in ((0, 1), (2, 3), (4, 6), (7, 9), (10, 1 << 30)):
+            m = (refs >= lo_) & (refs <= hi_)
+            if m.any():
+                print("  %4d streams with %s refinements: duration mean %.1f max %.1f us"
+                      % (m.sum(), ("%d-%d" % (lo_, hi_)) if hi_ < 1 << 20 else ">= %d" % lo_, dur[m].mean(), dur[m].max()))
         for xcd in range(8):
             m = xcc == xcd
             if m.any():
