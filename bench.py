@@ -49,6 +49,8 @@ sys.path.insert(0, ROOT)
 
 NSAMPLES = int(os.environ.get("MIFSK_BENCH_NSAMPLES", "480000"))	# 10 s at 48 kHz (override: experiments only)
 HBM_PEAK = 8.0e12		# B/s, MI355X spec (MI355X_MICROARCH.md)
+PCIE_PEAK = 63.0e9		# B/s, PCIe gen5 x16 per direction
+WORLDLOADS_DEFAULT_STREAMS = 1024
 
 # name -> (BASELINE.json entry, rx mode, streams per GPU, seconds, word range, amplitude)
 WORKLOADS = {
@@ -195,50 +197,24 @@ def hbm_traffic(name):
     under profiles/ for this workload by tools/profile_round.sh -- reported only while the record
     was taken with the kernel sources that are running now; None otherwise (a stale ratio would
     silently survive a kernel change)."""
-    path = os.path.join(ROOT, "profiles", "r02_%s_hbm_traffic.json" % name)
+    path = os.path.join(ROOT, "profiles", "r03_%s_hbm_traffic.json" % name)
     try:
         with open(path) as f:
             rec = json.load(f)
         if rec.get("kernel_source_id") != kernel_source_id():
             return None
         return {"bytes_per_launch": rec["hbm_bytes_per_launch"],
-                "source": "profiles/r02_%s_hbm_traffic.json" % name,
+                "source": "profiles/r03_%s_hbm_traffic.json" % name,
                 "fetch_size_kb_raw": rec["fetch_size_kb_raw"], "write_size_kb_raw": rec["write_size_kb_raw"]}
     except Exception:
         return None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="1200", choices=sorted(WORKLOADS))
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
-    ap.add_argument("--streams", type=int, default=0, help="streams per GPU (default: the config's)")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--engine", default=None, choices=["wave", "workgroup"],
-                    help="force a receive-loop engine (default: the library chooses)")
-    args = ap.parse_args()
-
-    import torch
-    import minimodem_amd as M
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, "WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus)
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-
-    name = args.config
+def run_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, cpu_leg):
+    """One BASELINE entry on this rank's shard: synthesize the batch on the device (or host for
+    configs[1]), W untimed + K timed passes bracketed by barrier + synchronize, kernel time by
+    events on the launch stream.  Returns the JSON line as a dict on rank 0, None elsewhere."""
     entry, mode, per_gpu, seconds, _, amplitude = WORKLOADS[name]
-    ctx = M.Context(local_rank)
     cfg = M.rx_config(mode)
     per_gpu = args.streams or per_gpu
     if args.scaling == "strong":
@@ -324,7 +300,7 @@ def main():
                     w.wait()
                 pending[b] = None
 
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(i)
     drain()
     torch.cuda.synchronize()
@@ -333,9 +309,9 @@ def main():
     torch.cuda.synchronize()
 
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-           for _ in range(args.steps)]
+           for _ in range(steps)]
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         step(i, evs[i])
     drain()
     torch.cuda.synchronize()
@@ -354,7 +330,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         total_samples = float(t.item())
 
-    last = (args.steps - 1) & 1 if args.steps else 0
+    last = (steps - 1) & 1 if steps else 0
     res = M.results_to_host(bufs[last])
     gpu_bytes, gpu_nbytes = res["bytes"], res["nbytes"]
 
@@ -364,9 +340,7 @@ def main():
             return got == payload.tobytes()
         if name == "same" and SAME_CONDITIONS[gid % 8] in (("snr_db", 12), ("snr_db", 9), ("snr_db", 6), ("snr_db", 3)):
             return None				# whether it survives the noise is not a criterion
-        if name == "rtty":
-            return payload.tobytes() in got	# (5-bit words; the leader may add a frame in front)
-        return payload.tobytes() in got
+        return payload.tobytes() in got		# (rtty: 5-bit words; the leader may add a frame in front)
 
     verdicts = [stream_ok(gpu_bytes[i], int(gpu_nbytes[i]), payloads[i], lo + i) for i in range(nstreams)]
     ok_streams = sum(1 for v in verdicts if v)
@@ -393,16 +367,17 @@ def main():
                     peers_judged += 1
                     peers_ok += bool(v)
 
+    line = None
     if rank == 0:
-        value = total_samples * args.steps / dt
+        value = total_samples * steps / dt
         kavg = float(np.mean(kernel_ms)) * 1e-3
         achieved = total_samples_local * 4.0 / kavg
         launch = M.demod_plan(ctx, cfg, nstreams, engine=args.engine)	# what the library launches
         line = {
             "metric": "audio samples/sec demodulated (whole node), %s-baud 48 kHz f32"
                       % {"1200": "1200", "rtty": "45.45", "12000": "12000", "same": "520.83"}[name],
-            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s; %d streams x %d samples per GPU (BASELINE.json)"
@@ -422,7 +397,7 @@ def main():
         }
         if world > 1:
             line["payload_roundtrip_ok_streams_gathered_from_peers"] = "%d/%d" % (peers_ok, peers_judged)
-        if world == 1 and not args.no_cpu:
+        if world == 1 and cpu_leg:
             # a bounded sample of the same batch on the host cores
             k = nstreams if name == "1200" else {"rtty": 256, "12000": 1024, "same": 512}[name]
             k = min(k, nstreams)
@@ -439,6 +414,158 @@ def main():
                         for i in range(k)]
             line.update(cpu_baselines(name, mode, int(cfg.sample_rate), hs, hl, gpu_bytes, gpu_nbytes,
                                       gpu_text))
+        if world == 1 and name == "1200" and not args.no_h2d:
+            line["h2d_inclusive"] = h2d_inclusive(M, torch, ctx, cfg, samples, nsamp, frames_cap, gpu_bytes,
+                                                  gpu_nbytes)
+    del samples, bufs
+    torch.cuda.empty_cache()
+    return line
+
+
+def h2d_inclusive(M, torch, ctx, cfg, samples, nsamp, frames_cap, gpu_bytes, gpu_nbytes):
+    """SURVEY 8(d)'s third timing: the same batch starting in HOST memory (pinned), through the
+    library's pipelined host entry -- chunked H2D on a copy stream overlapped with the demod of
+    the chunk before, results copied back -- once as f32 (4 B per sample over PCIe) and once as
+    the S16 a WAV file holds (2 B per sample, converted on the device).  Never `value`."""
+    out = {"unit": "samples/s", "pcie_peak_GBps": PCIE_PEAK / 1e9}
+    nstreams = samples.shape[0]
+    for fmt in ("f32", "s16"):
+        try:
+            if fmt == "f32":
+                host = M.host_alloc((nstreams, samples.shape[1]), np.float32)
+                host[:] = samples.cpu().numpy()
+            else:
+                host = M.host_alloc((nstreams, samples.shape[1]), np.int16)
+                host[:] = torch.round(samples * 32767.0).to(torch.int16).cpu().numpy()
+            best = None
+            for _ in range(3):
+                t0 = time.perf_counter()
+                r = M.demod_batch_host(ctx, cfg, host, frames_cap=frames_cap, episodes_cap=8,
+                                       want=("bytes",))
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            ok = sum(1 for i in range(nstreams)
+                     if r["bytes"][i, :int(r["nbytes"][i])].tobytes()
+                     == gpu_bytes[i, :int(gpu_nbytes[i])].tobytes())
+            bps = 4.0 if fmt == "f32" else 2.0
+            out[fmt] = {"value": nstreams * nsamp / best, "seconds": best,
+                        "pcie_GBps": nstreams * nsamp * bps / best / 1e9,
+                        "frac_of_pcie_peak": nstreams * nsamp * bps / best / PCIE_PEAK,
+                        "streams_equal_to_resident_run": "%d/%d" % (ok, nstreams)}
+            M.host_free(host)
+        except Exception as e:					# noqa: BLE001 -- a diagnostic leg must not kill the line
+            out[fmt] = {"error": repr(e)}
+    return out
+
+
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks
+    ourselves (one process per GPU, rendezvous on 127.0.0.1) and pass their output through."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default=None, choices=sorted(WORKLOADS),
+                    help="one BASELINE entry only (default: configs[1] as the line, the others "
+                         "with a few steps each under its \"configs\" key)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--streams", type=int, default=0, help="streams per GPU (default: the config's)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the H2D-inclusive leg")
+    ap.add_argument("--no-extra", action="store_true", help="configs[1] only: skip configs[2..4]")
+    ap.add_argument("--engine", default=None, choices=["wave", "workgroup"],
+                    help="force a receive-loop engine (default: the library chooses)")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(respawn_under_torchrun(args))
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, "WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus)
+
+    if os.environ.get("MIFSK_BENCH_DRYRUN"):
+        # the launch path without a GPU (tests/test_distributed_cpu.py): rendezvous over gloo,
+        # shard the batch, reduce, print -- everything bench.py does around the kernels
+        import torch
+        import torch.distributed as dist
+        import minimodem_amd as M
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        lo, hi = M.shard_range(WORLDLOADS_DEFAULT_STREAMS * world, rank, world)
+        t = torch.tensor([float(hi - lo)], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "total_streams": int(t.item()),
+                              "launcher": os.environ.get("TORCHELASTIC_RUN_ID", "") != "" or world == 1}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    import torch
+    import minimodem_amd as M
+
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    ctx = M.Context(local_rank)
+
+    name = args.config or "1200"
+    line = run_workload(name, args, M, torch, dist, ctx, rank, world, args.steps, args.warmup,
+                        cpu_leg=not args.no_cpu)
+    if args.config is None and not args.no_extra:
+        # the other BASELINE entries at their stated per-GPU sizes, a few timed passes each, device
+        # generator, no CPU leg: driver-visible kernel time and roofline fraction per entry
+        extra = {}
+        for other in ("rtty", "12000", "same"):
+            try:
+                sub = run_workload(other, args, M, torch, dist, ctx, rank, world,
+                                   max(1, min(5, args.steps)), 1, cpu_leg=False)
+            except Exception as e:				# noqa: BLE001
+                sub = {"error": repr(e)} if rank == 0 else None
+            if rank == 0 and sub is not None:
+                if "error" in sub:
+                    extra[other] = sub
+                    continue
+                rf = sub["roofline"]
+                extra[other] = {
+                    "workload": sub["config"]["workload"], "value": sub["value"], "unit": sub["unit"],
+                    "steps": sub["steps"], "ms_per_step": sub["ms_per_step"],
+                    "kernel": rf["kernel"], "kernel_ms_avg": rf["kernel_ms_avg"],
+                    "algorithmic_bytes_per_launch": rf["algorithmic_bytes_per_launch"],
+                    "roofline": {"bound": "hbm", "achieved": rf["achieved"], "peak": rf["peak"],
+                                 "unit": rf["unit"], "frac": rf["frac"], "traffic": rf["traffic"]},
+                    "launch": rf["launch"],
+                    "payload_roundtrip_ok_streams": sub["payload_roundtrip_ok_streams"],
+                }
+                if "payload_roundtrip_ok_streams_gathered_from_peers" in sub:
+                    extra[other]["payload_roundtrip_ok_streams_gathered_from_peers"] = \
+                        sub["payload_roundtrip_ok_streams_gathered_from_peers"]
+        if rank == 0:
+            line["configs"] = extra
+    if rank == 0:
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

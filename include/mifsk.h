@@ -21,7 +21,9 @@
  *   mifsk_ctx_create/destroy      fsk_plan_new/destroy   fsk.c:33-104
  *   mifsk_find_frame_batch        fsk_find_frame         fsk.c:449-538 (N problems)
  *   mifsk_demod_batch             the --rx main loop     minimodem.c:1137-1463
- *   mifsk_demod_batch_host        same, host buffers     (H2D + demod + D2H)
+ *   mifsk_demod_batch_host[_ex]   same, host buffers     (chunked H2D | demod | D2H, overlapped)
+ *   mifsk_demod_files             --rx --file, N files   simpleaudio-sndfile.c:42-74,
+ *                                                        minimodem.c:1014-1032
  */
 #ifndef MIFSK_H
 #define MIFSK_H
@@ -34,7 +36,7 @@ extern "C" {
 #endif
 
 #define MIFSK_MAX_FRAME_BITS	64	/* fsk.c:185-187,463 */
-#define MIFSK_ABI_VERSION	3
+#define MIFSK_ABI_VERSION	4
 
 /* which databits decoder main() would have selected (minimodem.c:549-553,
  * 675,820,856,866,892).  Decoding frame bits to text is O(1)/frame host work
@@ -295,10 +297,46 @@ typedef struct mifsk_launch_info {
 int mifsk_demod_plan( mifsk_ctx *ctx, const mifsk_rx_config *cfg, int nstreams,
 	unsigned flags, mifsk_launch_info *out );
 
-/* Same, for HOST pointers in `io` (all fields, d_ prefix notwithstanding):
- * copies in, runs mifsk_demod_batch, copies out, synchronises. */
+/* ---- streams that start in host memory (SURVEY 8 d "H2D-inclusive") -------- */
+
+/* Same, for HOST pointers in `io` (all fields, d_ prefix notwithstanding).  The
+ * batch is cut into chunks of whole streams (~64 MB of input); chunk k+1 crosses
+ * PCIe on a copy stream while chunk k is demodulated and chunk k-1's results are
+ * copied back, so the call runs at the speed of the bus.  Input rows in
+ * page-locked memory (mifsk_host_alloc, hipHostMalloc, hipHostRegister) are
+ * copied by DMA from where they are; anything else is first moved into the
+ * context's own pinned staging buffers by worker threads.  Synchronous: results
+ * are in place on return.  One host call at a time per context (calls on one
+ * context serialise; use one context per device and per concurrent caller). */
 int mifsk_demod_batch_host( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
 	const mifsk_demod_io *io );
+
+/* `io->d_samples` points to int16_t rows (`stream_stride` counts int16 elements):
+ * PCM16 as a WAV file holds it.  It crosses the bus as 16-bit and is converted on
+ * the device the way libsndfile converts it for the reference (value / 32768,
+ * simpleaudio-sndfile.c:42-56).  Host entry points only. */
+#define MIFSK_IO_HOST_S16	0x100u
+
+typedef struct mifsk_host_stats {
+    double	seconds_total;		/* wall time of the call                          */
+    double	seconds_staging;	/* of which: worker threads filling pinned memory */
+    uint64_t	bytes_h2d, bytes_d2h;
+    uint32_t	chunks, streams;
+    uint32_t	source_pinned;		/* 1: input rows were DMA'd from the caller's memory */
+    uint32_t	reserved;
+} mifsk_host_stats;
+
+/* ... with the --Xrxnoise term (0 = off; see mifsk_ingest_s16) applied on the
+ * device, and what the pipeline did reported in *stats (may be NULL). */
+int mifsk_demod_batch_host_ex( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
+	const mifsk_demod_io *io, float rxnoise, mifsk_host_stats *stats );
+
+/* page-locked host memory for the inputs of the host entry points */
+void *mifsk_host_alloc( size_t bytes );
+void  mifsk_host_free( void *p );
+
+/* upper bound on carrier episodes one stream of nsamples can yield */
+size_t mifsk_max_episodes( const mifsk_rx_config *cfg, size_t nsamples );
 
 /* ---- several GPUs (SURVEY 8 e) -------------------------------------------- */
 
@@ -385,6 +423,48 @@ int mifsk_ingest_s16( mifsk_ctx *ctx, const int16_t *d_pcm, size_t pcm_stride,
 /* the --Xrxnoise term alone, in place, for input that is already float */
 int mifsk_ingest_rxnoise_f32( mifsk_ctx *ctx, float *d_samples, size_t stream_stride,
 	const uint32_t *d_nsamples, uint32_t nsamples, int nstreams, float rxnoise, void *stream );
+
+/* ---- a list of audio files -> one batch ----------------------- */
+
+/* `minimodem --rx --file F <mode>` for N files at once (reference:
+ * simpleaudio-sndfile.c:113-160 open, :42-74 read, minimodem.c:1014-1032): every
+ * file's RIFF/WAVE header is parsed (PCM16 or float32, mono), the files are
+ * grouped by (sample rate, sample format) -- the reference takes the sample rate
+ * from the file and derives the whole configuration from it, so each group gets
+ * its own mifsk_rx_config from `args` -- and each group runs through the host
+ * pipeline above: worker threads pread() the RAW samples into pinned memory, they
+ * cross PCIe as they are in the file, PCM16 is converted and --Xrxnoise added on
+ * the device, and the receive loop runs over the chunk while the next one is read
+ * and copied.  Results are owned by the returned object. */
+typedef struct mifsk_file_result {
+    int			error;		/* 0, or -errno: open/read failed, not a WAV
+					   (-EINVAL), unsupported format (-ENOTSUP)  */
+    mifsk_wav_info	info;
+    const mifsk_rx_config *cfg;		/* the configuration this file was decoded
+					   with (its sample rate); NULL on error     */
+    uint32_t		nframes, nbytes, nepisodes;
+    uint32_t		status;		/* MIFSK_STREAM_*                            */
+    int32_t		carrier_band;	/* --auto-carrier (see mifsk_demod_io)       */
+    uint32_t		reserved;
+    const uint64_t	*bits;		/* [nframes] data bits of every frame        */
+    const uint8_t	*bytes;		/* [nbytes]                                  */
+    const mifsk_frame	*frames;	/* [nframes], or NULL without WANT_FRAMES    */
+    const mifsk_episode	*episodes;	/* [nepisodes]                               */
+} mifsk_file_result;
+
+typedef struct mifsk_files mifsk_files;
+
+#define MIFSK_FILES_WANT_FRAMES	0x1000u	/* keep the per-frame records too */
+
+/* flags: MIFSK_IO_RING_EXACT / _ENGINE_* / MIFSK_FILES_*.  Returns 0 when the
+ * batch ran (per-file failures are in mifsk_file_result.error), -errno when it
+ * could not. */
+int mifsk_demod_files( mifsk_ctx *ctx, const mifsk_modem_args *args,
+	const char *const *paths, int nfiles, float rxnoise, unsigned flags, mifsk_files **out );
+int mifsk_files_count( const mifsk_files *f );
+const mifsk_file_result *mifsk_files_get( const mifsk_files *f, int i );
+const mifsk_host_stats *mifsk_files_stats( const mifsk_files *f );
+void mifsk_files_free( mifsk_files *f );
 
 /* ---- transmit side (test and benchmark input generator) ------------------ */
 

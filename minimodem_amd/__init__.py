@@ -144,8 +144,10 @@ def demod_batch(ctx, cfg, samples, nsamples=None, want=("bytes", "episodes"),
     assert samples.stride(1) == 1
     nstreams, width = samples.shape
     _check_nsamples(torch, nsamples, nstreams)     # (the kernels clamp lengths to the row width)
-    # (a lone row's stride is arbitrary in torch: numpy's x[None, :] has stride 0)
-    stride = samples.stride(0) if nstreams > 1 else (int(width) + 3) & ~3
+    # (a lone row's stride is arbitrary in torch -- numpy's x[None, :] has stride 0 -- so its
+    # width stands in for it: the kernels read whole float4s, the row must hold them)
+    assert nstreams > 1 or width % 4 == 0, "a lone row must be padded to a multiple of 4 samples"
+    stride = samples.stride(0) if nstreams > 1 else int(width)
     n_uniform = int(width)
     if frames_cap is None:
         frames_cap = max_frames(cfg, n_uniform)
@@ -532,29 +534,68 @@ def synthesize_batch(ctx, cfg, words, nwords=None, lut=4096, amplitude=1.0, lead
     return out, lens
 
 
+_PINNED = {}
+
+
+def host_alloc(shape, dtype=np.float32):
+    """A numpy array in page-locked host memory (mifsk_host_alloc): input rows the host entry
+    points copy by DMA from where they are.  Release with host_free()."""
+    shape = tuple(int(v) for v in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+    dtype = np.dtype(dtype)
+    nbytes = int(np.prod(shape)) * dtype.itemsize
+    ptr = _lib.load().mifsk_host_alloc(max(nbytes, 1))
+    if not ptr:
+        raise MemoryError("mifsk_host_alloc(%d)" % nbytes)
+    buf = (C.c_char * max(nbytes, 1)).from_address(ptr)
+    arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+    _PINNED[arr.ctypes.data] = ptr
+    return arr
+
+
+def host_free(arr):
+    ptr = _PINNED.pop(arr.ctypes.data, None)
+    if ptr:
+        _lib.load().mifsk_host_free(ptr)
+
+
+def max_episodes(cfg, nsamples):
+    return int(_lib.load().mifsk_max_episodes(C.byref(cfg), int(nsamples)))
+
+
 def demod_batch_host(ctx, cfg, samples, nsamples=None, frames_cap=None, episodes_cap=8,
-                     ring_exact=False):
-    """mifsk_demod_batch_host: the whole batch from HOST memory in one call (copies
-    in, runs the receive loop on the device, copies out, synchronises).  samples is a
-    float32 numpy array [nstreams, stride]; returns a dict of numpy arrays.
-    `ctx` may be a list of Contexts (one per GPU): mifsk_demod_batch_host_multi
-    shards the streams over them (mifsk_shard_range) inside this one process."""
+                     ring_exact=False, want=("bytes", "bits", "frames", "episodes"), rxnoise=0.0,
+                     stats=False, engine=None):
+    """mifsk_demod_batch_host[_ex]: the whole batch from HOST memory in one call -- chunks of
+    streams cross PCIe on a copy stream while the chunk before is demodulated and the one
+    before that is copied back.  samples is a float32 numpy array [nstreams, stride], or
+    int16 (PCM16 as a WAV file holds it: MIFSK_IO_HOST_S16, converted on the device); rows
+    from host_alloc() are copied by DMA from where they are.  Returns a dict of numpy arrays
+    (plus "stats" when asked).  `ctx` may be a list of Contexts (one per GPU):
+    mifsk_demod_batch_host_multi shards the streams over them inside this one process."""
     lib = _lib.load()
-    samples = np.ascontiguousarray(samples, dtype=np.float32)
+    s16 = samples.dtype == np.int16
+    if not (s16 or (samples.dtype == np.float32 and samples.flags.c_contiguous)):
+        samples = np.ascontiguousarray(samples, dtype=np.float32)
+    assert samples.ndim == 2 and samples.flags.c_contiguous
     nstreams, stride = samples.shape
     if frames_cap is None:
         frames_cap = max_frames(cfg, stride)
-    res = {
-        "bytes": np.zeros((nstreams, frames_cap), np.uint8),
-        "nbytes": np.zeros(nstreams, np.uint32),
-        "bits": np.zeros((nstreams, frames_cap), np.uint64),
-        "frames": np.zeros((nstreams, frames_cap), FRAME_DTYPE),
-        "nframes": np.zeros(nstreams, np.uint32),
-        "episodes": np.zeros((nstreams, episodes_cap), EPISODE_DTYPE),
-        "nepisodes": np.zeros(nstreams, np.uint32),
-        "status": np.zeros(nstreams, np.uint32),
-        "carrier_band": np.full(nstreams, -1, np.int32),
-    }
+    res = {"nframes": np.zeros(nstreams, np.uint32), "status": np.zeros(nstreams, np.uint32),
+           "carrier_band": np.full(nstreams, -1, np.int32)}
+    if "bytes" in want:
+        res["bytes"] = np.zeros((nstreams, frames_cap), np.uint8)
+        res["nbytes"] = np.zeros(nstreams, np.uint32)
+    if "bits" in want:
+        res["bits"] = np.zeros((nstreams, frames_cap), np.uint64)
+    if "frames" in want:
+        res["frames"] = np.zeros((nstreams, frames_cap), FRAME_DTYPE)
+    if "episodes" in want:
+        res["episodes"] = np.zeros((nstreams, episodes_cap), EPISODE_DTYPE)
+        res["nepisodes"] = np.zeros(nstreams, np.uint32)
+
+    def ptr(name):
+        return res[name].ctypes.data if name in res else None
+
     io = _lib.DemodIO()
     io.d_samples = samples.ctypes.data
     io.stream_stride = stride
@@ -563,23 +604,87 @@ def demod_batch_host(ctx, cfg, samples, nsamples=None, frames_cap=None, episodes
         io.d_nsamples = nsamples.ctypes.data
     io.nsamples = stride
     io.nstreams = nstreams
-    io.d_bytes = res["bytes"].ctypes.data
-    io.d_nbytes = res["nbytes"].ctypes.data
-    io.d_bits = res["bits"].ctypes.data
-    io.d_frames = res["frames"].ctypes.data
-    io.d_nframes = res["nframes"].ctypes.data
+    io.d_bytes = ptr("bytes")
+    io.d_nbytes = ptr("nbytes")
+    io.d_bits = ptr("bits")
+    io.d_frames = ptr("frames")
+    io.d_nframes = ptr("nframes")
     io.frames_cap = frames_cap
-    io.d_episodes = res["episodes"].ctypes.data
-    io.d_nepisodes = res["nepisodes"].ctypes.data
+    io.d_episodes = ptr("episodes")
+    io.d_nepisodes = ptr("nepisodes")
     io.episodes_cap = episodes_cap
-    io.d_status = res["status"].ctypes.data
-    io.d_carrier_band = res["carrier_band"].ctypes.data
-    io.flags = _lib.IO_RING_EXACT if ring_exact else 0
+    io.d_status = ptr("status")
+    io.d_carrier_band = ptr("carrier_band")
+    io.flags = (_lib.IO_RING_EXACT if ring_exact else 0) | (_lib.IO_HOST_S16 if s16 else 0) | \
+        (_lib.IO_ENGINE_WORKGROUP if engine == "workgroup" else 0) | \
+        (_lib.IO_ENGINE_WAVE if engine == "wave" else 0)
     if isinstance(ctx, (list, tuple)):
+        assert not s16 and not rxnoise
         handles = (C.c_void_p * len(ctx))(*[c.handle for c in ctx])
         rc = lib.mifsk_demod_batch_host_multi(handles, len(ctx), C.byref(cfg), C.byref(io))
     else:
-        rc = lib.mifsk_demod_batch_host(ctx.handle, C.byref(cfg), C.byref(io))
+        st = _lib.HostStats()
+        rc = lib.mifsk_demod_batch_host_ex(ctx.handle, C.byref(cfg), C.byref(io), C.c_float(rxnoise),
+                                           C.byref(st))
+        if stats:
+            res["stats"] = {k: getattr(st, k) for k, _ in st._fields_ if k != "reserved"}
     if rc != 0:
         raise RuntimeError("mifsk_demod_batch_host failed: %d" % rc)
     return res
+
+
+def demod_files(ctx, paths, baudmode="1200", rxnoise=0.0, ring_exact=False, want_frames=False,
+                engine=None, **opts):
+    """mifsk_demod_files: `minimodem --rx --file F <baudmode>` for a list of WAV files (PCM16 or
+    float32, any mix of lengths and sample rates) as batches on the device: raw samples are
+    pread() into pinned memory by worker threads, cross PCIe as they are in the file and are
+    converted there.  Returns (list of per-file dicts, stats dict); a file that could not be
+    decoded has {"error": -errno}.  Each dict carries the RxConfig it was decoded with."""
+    lib = _lib.load()
+    a = ModemArgs()
+    lib.mifsk_modem_args_default(C.byref(a))
+    a.baudmode = str(baudmode).encode()
+    if "sync_byte" in opts:
+        a.have_sync_byte = 1
+    for k, v in opts.items():
+        if not hasattr(a, k):
+            raise TypeError("unknown modem option %r" % k)
+        setattr(a, k, v)
+    enc = [os.fsencode(p) for p in paths]
+    arr = (C.c_char_p * max(1, len(enc)))(*enc)
+    flags = (_lib.IO_RING_EXACT if ring_exact else 0) | (_lib.FILES_WANT_FRAMES if want_frames else 0) | \
+        (_lib.IO_ENGINE_WORKGROUP if engine == "workgroup" else 0) | \
+        (_lib.IO_ENGINE_WAVE if engine == "wave" else 0)
+    h = C.c_void_p()
+    rc = lib.mifsk_demod_files(ctx.handle, C.byref(a), arr, len(enc), C.c_float(rxnoise), flags, C.byref(h))
+    if rc != 0:
+        if h:
+            lib.mifsk_files_free(h)
+        raise RuntimeError("mifsk_demod_files failed: %d" % rc)
+    out = []
+    try:
+        for i in range(lib.mifsk_files_count(h)):
+            fr = lib.mifsk_files_get(h, i).contents
+            d = {"error": fr.error, "path": paths[i],
+                 "info": {k: getattr(fr.info, k) for k, _ in fr.info._fields_}}
+            if fr.error == 0:
+                cfg = RxConfig()
+                C.memmove(C.byref(cfg), fr.cfg, C.sizeof(RxConfig))
+                d["cfg"] = cfg
+                d["status"] = fr.status
+                d["carrier_band"] = fr.carrier_band
+                d["bits"] = np.ctypeslib.as_array((C.c_uint64 * max(1, fr.nframes)).from_address(fr.bits))[:fr.nframes].copy()
+                d["bytes"] = bytes((C.c_uint8 * max(1, fr.nbytes)).from_address(fr.bytes))[:fr.nbytes]
+                d["episodes"] = np.frombuffer(
+                    (C.c_char * (max(1, fr.nepisodes) * EPISODE_DTYPE.itemsize)).from_address(fr.episodes),
+                    dtype=EPISODE_DTYPE)[:fr.nepisodes].copy()
+                if fr.frames:
+                    d["frames"] = np.frombuffer(
+                        (C.c_char * (max(1, fr.nframes) * FRAME_DTYPE.itemsize)).from_address(fr.frames),
+                        dtype=FRAME_DTYPE)[:fr.nframes].copy()
+            out.append(d)
+        st = lib.mifsk_files_stats(h).contents
+        stats = {k: getattr(st, k) for k, _ in st._fields_ if k != "reserved"}
+    finally:
+        lib.mifsk_files_free(h)
+    return out, stats

@@ -149,6 +149,15 @@ class LaunchInfo(C.Structure):
 IO_RING_EXACT = 1
 IO_ENGINE_WORKGROUP = 2
 IO_ENGINE_WAVE = 4
+IO_HOST_S16 = 0x100
+FILES_WANT_FRAMES = 0x1000
+
+
+class HostStats(C.Structure):
+    _fields_ = [("seconds_total", C.c_double), ("seconds_staging", C.c_double),
+                ("bytes_h2d", C.c_uint64), ("bytes_d2h", C.c_uint64),
+                ("chunks", C.c_uint32), ("streams", C.c_uint32),
+                ("source_pinned", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class FskPlan(C.Structure):
@@ -164,6 +173,14 @@ class FskPlan(C.Structure):
 class WavInfo(C.Structure):
     _fields_ = [("sample_rate", C.c_uint), ("channels", C.c_uint), ("bits_per_sample", C.c_uint),
                 ("is_float", C.c_int), ("data_offset", C.c_size_t), ("nframes", C.c_size_t)]
+
+
+class FileResult(C.Structure):
+    _fields_ = [("error", C.c_int), ("info", WavInfo), ("cfg", C.POINTER(RxConfig)),
+                ("nframes", C.c_uint32), ("nbytes", C.c_uint32), ("nepisodes", C.c_uint32),
+                ("status", C.c_uint32), ("carrier_band", C.c_int32), ("reserved", C.c_uint32),
+                ("bits", C.c_void_p), ("bytes", C.c_void_p), ("frames", C.c_void_p),
+                ("episodes", C.c_void_p)]
 
 
 assert C.sizeof(FskPlan) == 64 and FskPlan.fftplan.offset == 40
@@ -183,6 +200,9 @@ EXPORTS = [
     "mifsk_demod_batch_host_multi", "mifsk_demod_plan", "mifsk_stream_text",
     "mifsk_wav_parse", "mifsk_ingest_s16", "mifsk_ingest_rxnoise_f32",
     "mifsk_tx_synthesize_batch",
+    "mifsk_demod_batch_host_ex", "mifsk_host_alloc", "mifsk_host_free", "mifsk_max_episodes",
+    "mifsk_demod_files", "mifsk_files_count", "mifsk_files_get", "mifsk_files_stats",
+    "mifsk_files_free",
 ]
 
 _lib = None
@@ -259,5 +279,35 @@ def load():
         C.c_void_p, C.POINTER(RxConfig), C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_int,
         C.c_uint, C.c_float, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p,
         C.c_void_p]
+    lib.mifsk_demod_plan.restype = C.c_int
+    lib.mifsk_demod_plan.argtypes = [C.c_void_p, C.POINTER(RxConfig), C.c_int, C.c_uint,
+                                     C.POINTER(LaunchInfo)]
+    lib.mifsk_demod_batch_host_multi.restype = C.c_int
+    lib.mifsk_demod_batch_host_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(RxConfig),
+                                                 C.POINTER(DemodIO)]
+    lib.mifsk_databits_encode.restype = C.c_uint
+    lib.mifsk_databits_encode.argtypes = [C.c_void_p, C.POINTER(C.c_uint), C.c_char]
+    lib.mifsk_shard_range.restype = None
+    lib.mifsk_shard_range.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.mifsk_demod_batch_host_ex.restype = C.c_int
+    lib.mifsk_demod_batch_host_ex.argtypes = [C.c_void_p, C.POINTER(RxConfig), C.POINTER(DemodIO),
+                                              C.c_float, C.POINTER(HostStats)]
+    lib.mifsk_host_alloc.restype = C.c_void_p
+    lib.mifsk_host_alloc.argtypes = [C.c_size_t]
+    lib.mifsk_host_free.restype = None
+    lib.mifsk_host_free.argtypes = [C.c_void_p]
+    lib.mifsk_max_episodes.restype = C.c_size_t
+    lib.mifsk_max_episodes.argtypes = [C.POINTER(RxConfig), C.c_size_t]
+    lib.mifsk_demod_files.restype = C.c_int
+    lib.mifsk_demod_files.argtypes = [C.c_void_p, C.POINTER(ModemArgs), C.POINTER(C.c_char_p), C.c_int,
+                                      C.c_float, C.c_uint, C.POINTER(C.c_void_p)]
+    lib.mifsk_files_count.restype = C.c_int
+    lib.mifsk_files_count.argtypes = [C.c_void_p]
+    lib.mifsk_files_get.restype = C.POINTER(FileResult)
+    lib.mifsk_files_get.argtypes = [C.c_void_p, C.c_int]
+    lib.mifsk_files_stats.restype = C.POINTER(HostStats)
+    lib.mifsk_files_stats.argtypes = [C.c_void_p]
+    lib.mifsk_files_free.restype = None
+    lib.mifsk_files_free.argtypes = [C.c_void_p]
     _lib = lib
     return lib

@@ -19,6 +19,7 @@
 #include "fsk.h"
 #include "mifsk.h"
 #include "mifsk_device.h"
+#include "mifsk_ctx.h"
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
@@ -100,6 +101,14 @@ void fill_devcfg( DevCfg &d, const mifsk_rx_config &c )
 	};
 	d.skew = cost(1) < cost(0) ? 1u : 0u;
     }
+    for ( int i = 0; i < 4; i++ ) {
+	const unsigned f = c.try_first[i & 1], mx = c.try_max[i & 1];
+	const unsigned st = ( i & 2 ) ? c.try_step_fine[i & 1] : c.try_step[i & 1];
+	if ( (int)f < (int)mx && st ) {
+	    d.zz_up[i] = ( mx - f - 1 ) / st + 1;
+	    d.zz_down[i] = d.zz_up[i] - 1 < f / st ? d.zz_up[i] - 1 : f / st;
+	}
+    }
     d.div_magic = c.bit_nsamples > 1 ? (uint32_t)( 0x100000000ULL / c.bit_nsamples ) : 0xFFFFFFFFu;
     // minimodem.c:1407 with frame_start == try_first (carrier)
     d.lock_advance = c.try_first[1] + c.frame_nsamples - c.nsamples_overscan;
@@ -149,42 +158,6 @@ using mifsk::DevCfg;
 // ---------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------
-
-struct TwKey {
-    unsigned fftsize, b_mark, b_space, bit_nsamples;
-    bool operator==( const TwKey &o ) const
-    {
-	return fftsize == o.fftsize && b_mark == o.b_mark && b_space == o.b_space
-	    && bit_nsamples == o.bit_nsamples;
-    }
-};
-
-struct TwEntry {
-    TwKey	key;
-    double	*d_tw;
-};
-
-// device-resident copies of the kernel configuration, one per distinct config
-struct CfgEntry {
-    DevCfg	host;
-    DevCfg	*dev;
-};
-
-struct mifsk_ctx {
-    int			device;
-    int			ncu;		// compute units (occupancy planning)
-    char		name[256];
-    std::mutex		lock;
-    std::vector<TwEntry>	tables;
-    std::vector<CfgEntry>	configs;
-    // spectrum table for fsk_detect_carrier
-    unsigned		cs_fftsize;
-    double		*d_cs;
-};
-
-#define HIP_OK(call)	do { hipError_t e_ = (call); if ( e_ != hipSuccess ) { \
-	fprintf(stderr, "mifsk: %s failed: %s\n", #call, hipGetErrorString(e_)); \
-	return -EIO; } } while (0)
 
 int mifsk::ctx_device( const mifsk_ctx *ctx ) { return ctx->device; }
 
@@ -236,6 +209,8 @@ extern "C" void mifsk_ctx_destroy( mifsk_ctx *ctx )
 	(void)hipFree(e.dev);
     if ( ctx->d_cs )
 	(void)hipFree(ctx->d_cs);
+    if ( ctx->host )
+	mifsk::host_work_destroy(ctx->host);
     delete ctx;
 }
 
@@ -326,7 +301,7 @@ static int get_cs( mifsk_ctx *ctx, unsigned N, const double **d_out )
     return 0;
 }
 
-static int check_cfg( const mifsk_rx_config *cfg )
+int mifsk_check_cfg( const mifsk_rx_config *cfg )
 {
     if ( !cfg || cfg->expect_n_bits == 0 || cfg->expect_n_bits > MIFSK_MAX_FRAME_BITS
 	    || cfg->bit_nsamples == 0 || cfg->fftsize < 2 )
@@ -342,7 +317,7 @@ extern "C" int mifsk_find_frame_batch( mifsk_ctx *ctx, const mifsk_rx_config *cf
 	const float *d_samples, const mifsk_search *d_problems,
 	mifsk_search_result *d_results, int nproblems, void *stream )
 {
-    if ( !ctx || check_cfg(cfg) || ( nproblems > 0 && ( !d_samples || !d_problems || !d_results ) ) )
+    if ( !ctx || mifsk_check_cfg(cfg) || ( nproblems > 0 && ( !d_samples || !d_problems || !d_results ) ) )
 	return -EINVAL;
     HIP_OK(hipSetDevice(ctx->device));
     const double *d_tw = nullptr;
@@ -449,7 +424,7 @@ static int demod_batch_wave( mifsk_ctx *ctx, const mifsk_rx_config *cfg, const D
 extern "C" int mifsk_demod_batch( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
 	const mifsk_demod_io *io, void *stream )
 {
-    if ( !ctx || !io || check_cfg(cfg) )
+    if ( !ctx || !io || mifsk_check_cfg(cfg) )
 	return -EINVAL;
     if ( io->nstreams < 0 || ( io->nstreams > 0 && !io->d_samples ) )
 	return -EINVAL;
@@ -485,7 +460,7 @@ extern "C" int mifsk_demod_batch( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
 extern "C" int mifsk_demod_plan( mifsk_ctx *ctx, const mifsk_rx_config *cfg, int nstreams,
 	unsigned flags, mifsk_launch_info *out )
 {
-    if ( !ctx || !out || check_cfg(cfg) || nstreams < 0 )
+    if ( !ctx || !out || mifsk_check_cfg(cfg) || nstreams < 0 )
 	return -EINVAL;
     DevCfg d;
     mifsk::fill_devcfg(d, *cfg);
@@ -513,88 +488,6 @@ extern "C" int mifsk_demod_plan( mifsk_ctx *ctx, const mifsk_rx_config *cfg, int
     out->lattice_mode = li.lattice_mode;
     out->frames_per_block = li.frames_per_block;
     out->compute_units = (uint32_t)ctx->ncu;
-    return 0;
-}
-
-namespace {
-
-template <typename T>
-struct DevBuf {
-    T *p = nullptr;
-    ~DevBuf() { if ( p ) (void)hipFree(p); }
-    int alloc( size_t n ) { return hipMalloc(&p, ( n ? n : 1 ) * sizeof(T)) == hipSuccess ? 0 : -ENOMEM; }
-};
-
-} // namespace
-
-extern "C" int mifsk_demod_batch_host( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
-	const mifsk_demod_io *hio )
-{
-    if ( !ctx || !hio || check_cfg(cfg) || hio->nstreams < 0 )
-	return -EINVAL;
-    HIP_OK(hipSetDevice(ctx->device));
-    const size_t ns = (size_t)hio->nstreams;
-    if ( ns == 0 )
-	return 0;
-    // device rows: stride rounded up to 4 floats
-    uint32_t maxn = hio->nsamples;
-    if ( hio->d_nsamples ) {
-	maxn = 0;
-	for ( size_t i = 0; i < ns; i++ )
-	    maxn = hio->d_nsamples[i] > maxn ? hio->d_nsamples[i] : maxn;
-    }
-    const size_t dstride = ( (size_t)maxn + 3 ) & ~(size_t)3;
-    DevBuf<float> d_x;
-    DevBuf<uint32_t> d_n, d_nbytes, d_nframes, d_neps, d_status;
-    DevBuf<uint8_t> d_bytes;
-    DevBuf<uint64_t> d_bits;
-    DevBuf<mifsk_frame> d_frames;
-    DevBuf<mifsk_episode> d_eps;
-    DevBuf<uint64_t> d_cnt;
-    if ( d_x.alloc(ns * dstride ? ns * dstride : 4) )
-	return -ENOMEM;
-    if ( dstride ) {
-	HIP_OK(hipMemcpy2D(d_x.p, dstride * sizeof(float), hio->d_samples,
-			   hio->stream_stride * sizeof(float),
-			   ( hio->stream_stride < dstride ? hio->stream_stride : dstride ) * sizeof(float),
-			   ns, hipMemcpyHostToDevice));
-    }
-    mifsk_demod_io io = *hio;
-    io.d_samples = d_x.p;
-    io.stream_stride = dstride;
-    if ( hio->d_nsamples ) {
-	if ( d_n.alloc(ns) ) return -ENOMEM;
-	HIP_OK(hipMemcpy(d_n.p, hio->d_nsamples, ns * sizeof(uint32_t), hipMemcpyHostToDevice));
-	io.d_nsamples = d_n.p;
-    }
-    const size_t fc = hio->frames_cap, ec = hio->episodes_cap;
-    if ( hio->d_bytes )    { if ( d_bytes.alloc(ns * fc) ) return -ENOMEM;  io.d_bytes = d_bytes.p; }
-    if ( hio->d_bits )     { if ( d_bits.alloc(ns * fc) ) return -ENOMEM;   io.d_bits = d_bits.p; }
-    if ( hio->d_frames )   { if ( d_frames.alloc(ns * fc) ) return -ENOMEM; io.d_frames = d_frames.p; }
-    if ( hio->d_episodes ) { if ( d_eps.alloc(ns * ec) ) return -ENOMEM;    io.d_episodes = d_eps.p; }
-    if ( hio->d_nbytes )   { if ( d_nbytes.alloc(ns) ) return -ENOMEM;      io.d_nbytes = d_nbytes.p; }
-    if ( hio->d_nframes )  { if ( d_nframes.alloc(ns) ) return -ENOMEM;     io.d_nframes = d_nframes.p; }
-    if ( hio->d_nepisodes ){ if ( d_neps.alloc(ns) ) return -ENOMEM;        io.d_nepisodes = d_neps.p; }
-    if ( hio->d_status )   { if ( d_status.alloc(ns) ) return -ENOMEM;      io.d_status = d_status.p; }
-    if ( hio->d_counters ) { if ( d_cnt.alloc(ns * MIFSK_NCOUNTERS) ) return -ENOMEM; io.d_counters = d_cnt.p; }
-    DevBuf<int32_t> d_band;
-    if ( hio->d_carrier_band ) { if ( d_band.alloc(ns) ) return -ENOMEM; io.d_carrier_band = d_band.p; }
-
-    int rc = mifsk_demod_batch(ctx, cfg, &io, nullptr);
-    if ( rc )
-	return rc;
-    HIP_OK(hipDeviceSynchronize());
-    if ( hio->d_bytes )    HIP_OK(hipMemcpy(hio->d_bytes, d_bytes.p, ns * fc, hipMemcpyDeviceToHost));
-    if ( hio->d_bits )     HIP_OK(hipMemcpy(hio->d_bits, d_bits.p, ns * fc * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    if ( hio->d_frames )   HIP_OK(hipMemcpy(hio->d_frames, d_frames.p, ns * fc * sizeof(mifsk_frame), hipMemcpyDeviceToHost));
-    if ( hio->d_episodes ) HIP_OK(hipMemcpy(hio->d_episodes, d_eps.p, ns * ec * sizeof(mifsk_episode), hipMemcpyDeviceToHost));
-    if ( hio->d_nbytes )   HIP_OK(hipMemcpy(hio->d_nbytes, d_nbytes.p, ns * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    if ( hio->d_nframes )  HIP_OK(hipMemcpy(hio->d_nframes, d_nframes.p, ns * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    if ( hio->d_nepisodes )HIP_OK(hipMemcpy(hio->d_nepisodes, d_neps.p, ns * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    if ( hio->d_status )   HIP_OK(hipMemcpy(hio->d_status, d_status.p, ns * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    if ( hio->d_counters ) HIP_OK(hipMemcpy(hio->d_counters, d_cnt.p, ns * MIFSK_NCOUNTERS * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    if ( hio->d_carrier_band && cfg->auto_carrier_threshold > 0.0f )
-	HIP_OK(hipMemcpy(hio->d_carrier_band, d_band.p, ns * sizeof(int32_t), hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -634,7 +527,8 @@ extern "C" int mifsk_demod_batch_host_multi( mifsk_ctx *const *ctxs, int nctx,
 	mifsk_demod_io io = *hio;
 	const size_t o = (size_t)lo, fc = hio->frames_cap, ec = hio->episodes_cap;
 	io.nstreams = hi - lo;
-	io.d_samples = hio->d_samples + o * hio->stream_stride;
+	io.d_samples = (const float *)( (const char *)hio->d_samples
+					+ o * hio->stream_stride * ( ( hio->flags & MIFSK_IO_HOST_S16 ) ? 2u : 4u ) );
 	if ( io.d_nsamples )	 io.d_nsamples += o;
 	if ( io.d_bytes )	 io.d_bytes += o * fc;
 	if ( io.d_nbytes )	 io.d_nbytes += o;

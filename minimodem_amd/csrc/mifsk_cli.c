@@ -5,10 +5,13 @@
  * then for --rx runs its receive loop (:1137-1463) around fsk_find_frame() one
  * search at a time.  This program keeps the command line and replaces the loop:
  *
- *     read the whole file -> mifsk_demod_batch_host() (a batch of one stream: the
- *     receive loop runs on the MI355X) -> mifsk_stream_text() -> stdout / stderr
+ *     every --file of the command line -> mifsk_demod_files() (headers parsed, raw
+ *     samples through pinned memory to the MI355X, PCM16 -> float and --Xrxnoise on the
+ *     device, the receive loop over the batch) -> mifsk_stream_text() per file ->
+ *     stdout / stderr
  *
- * i.e. it is the binding a maintainer would put behind `--rx --file`, as code.
+ * i.e. it is the binding a maintainer would put behind `--rx --file`, as code;
+ * `--file a.wav --file b.wav ...` decodes a list of files as one batch.
  * --tx --file is served by the host transmitter (mifsk_tx_synthesize), so the
  * reference's own tests/self-test script runs against this binary unchanged
  * (MINIMODEM=.../minimodem_mifsk_batch; tests/test_gpu_cli.py).
@@ -32,39 +35,18 @@
 enum {
     OPT_MSBFIRST = 256, OPT_STARTBITS, OPT_STOPBITS, OPT_INVERT_START_STOP, OPT_SYNC_BYTE, OPT_LUT,
     OPT_FLOAT_SAMPLES, OPT_RX_ONE, OPT_BINARY_OUTPUT, OPT_BINARY_RAW, OPT_PRINT_FILTER, OPT_XRXNOISE,
-    OPT_RING_EXACT
+    OPT_RING_EXACT, OPT_FLAT, OPT_STATS
 };
 
 static void usage( void )
 {
     fprintf(stderr,
-	"usage: minimodem_mifsk_batch --rx|--tx --file FILE [options] {baudmode}\n"
+	"usage: minimodem_mifsk_batch --rx --file FILE [--file FILE ...] [options] {baudmode}\n"
+	"       minimodem_mifsk_batch --tx --file FILE [options] {baudmode}\n"
+	"       --flat         flat instead of ring-exact addressing past the end of the stream\n"
+	"       --batch-stats  print what the host pipeline moved\n"
 	"       (options of minimodem 0.24 that apply to audio files; see `minimodem --help`)\n");
     exit(1);
-}
-
-static void *read_whole_file( const char *path, size_t *len )
-{
-    FILE *f = fopen(path, "rb");
-    if ( !f )
-	return NULL;
-    size_t cap = 1 << 20, n = 0;
-    unsigned char *buf = malloc(cap);
-    for (;;) {
-	if ( n == cap ) {
-	    cap *= 2;
-	    buf = realloc(buf, cap);
-	}
-	if ( !buf )
-	    break;
-	size_t r = fread(buf + n, 1, cap - n, f);
-	n += r;
-	if ( r == 0 )
-	    break;
-    }
-    fclose(f);
-    *len = n;
-    return buf;
 }
 
 static void put_le( unsigned char *p, unsigned long v, int nbytes )
@@ -114,11 +96,15 @@ int main( int argc, char *argv[] )
 {
     int tx_mode = -1;
     const char *filename = NULL;
+    const char **files = NULL;
+    int nfiles = 0;
     mifsk_modem_args a;
     mifsk_modem_args_default(&a);
     float tx_amplitude = 1.0f;
     unsigned lut = 4096;
-    int float_samples = 0, quiet = 0, print_filter = 0, ring_exact = 0;
+    /* --rx reads past-the-end samples the way the reference's ring buffer does (RING
+     * addressing) unless --flat asks for the faster flat addressing */
+    int float_samples = 0, quiet = 0, print_filter = 0, flat = 0, stats = 0;
     float rxnoise = 0.0f;
 
     static struct option long_options[] = {
@@ -134,7 +120,7 @@ int main( int argc, char *argv[] )
 	{ "float-samples", 0, 0, OPT_FLOAT_SAMPLES }, { "rx-one", 0, 0, OPT_RX_ONE },
 	{ "binary-output", 0, 0, OPT_BINARY_OUTPUT }, { "binary-raw", 1, 0, OPT_BINARY_RAW },
 	{ "print-filter", 0, 0, OPT_PRINT_FILTER }, { "Xrxnoise", 1, 0, OPT_XRXNOISE },
-	{ "ring-exact", 0, 0, OPT_RING_EXACT },
+	{ "ring-exact", 0, 0, OPT_RING_EXACT }, { "flat", 0, 0, OPT_FLAT }, { "batch-stats", 0, 0, OPT_STATS },
 	{ 0 }
     };
     int c;
@@ -146,7 +132,11 @@ int main( int argc, char *argv[] )
 	case 'l': a.search_limit = (float)atof(optarg); break;
 	case 'a': a.auto_carrier_threshold = 0.001f; break;
 	case 'i': a.inverted_freqs = 1; break;
-	case 'f': filename = optarg; break;
+	case 'f':
+	    filename = optarg;
+	    files = realloc(files, (size_t)( nfiles + 1 ) * sizeof(*files));
+	    files[nfiles++] = optarg;
+	    break;
 	case '8': a.n_data_bits = 8; break;
 	case '7': a.n_data_bits = 7; break;
 	case '5': a.n_data_bits = 5; a.baudot = 1; break;
@@ -168,11 +158,13 @@ int main( int argc, char *argv[] )
 	case OPT_BINARY_RAW: a.binary_raw_nbits = atoi(optarg); break;
 	case OPT_PRINT_FILTER: print_filter = 1; break;
 	case OPT_XRXNOISE: rxnoise = (float)atof(optarg); break;
-	case OPT_RING_EXACT: ring_exact = 1; break;
+	case OPT_RING_EXACT: flat = 0; break;
+	case OPT_FLAT: flat = 1; break;
+	case OPT_STATS: stats = 1; break;
 	default: usage();
 	}
     }
-    if ( tx_mode < 0 || !filename || optind + 1 != argc )
+    if ( tx_mode < 0 || !filename || optind + 1 != argc || ( tx_mode == 1 && nfiles != 1 ) )
 	usage();
     a.baudmode = argv[optind];
 
@@ -215,84 +207,64 @@ int main( int argc, char *argv[] )
 	return rc ? 1 : 0;
     }
 
-    /* ---- receive: the whole file as a batch of one ------------------------------ */
-    size_t len = 0;
-    unsigned char *file = read_whole_file(filename, &len);
-    if ( !file ) {
-	perror(filename);
-	return 1;
-    }
-    mifsk_wav_info wi;
-    rc = mifsk_wav_parse(file, len, &wi);
-    if ( rc ) {
-	fprintf(stderr, "E: %s: not a mono PCM16 / float32 WAV file (%d)\n", filename, rc);
-	return 1;
-    }
-    if ( wi.sample_rate != cfg.sample_rate ) {
-	/* the reference takes the rate from the file (minimodem.c:1021-1032) */
-	a.sample_rate = wi.sample_rate;
-	if ( mifsk_rx_config_init(&cfg, &a) )
-	    return 1;
-    }
-    const size_t n = wi.nframes;
-    float *x = malloc(( n ? n : 1 ) * sizeof(float));
-    const unsigned char *d = file + wi.data_offset;
-    if ( wi.is_float ) {
-	memcpy(x, d, n * sizeof(float));
-    } else {
-	for ( size_t i = 0; i < n; i++ ) {		/* sf_readf_float on 16-bit input: / 32768 */
-	    short s = (short)( d[2 * i] | ( d[2 * i + 1] << 8 ) );
-	    x[i] = (float)s / 32768.0f;
-	}
-    }
-    if ( rxnoise != 0.0f ) {				/* simpleaudio-sndfile.c:64-69 */
-	const float f = rxnoise * 2;
-	for ( size_t i = 0; i < n; i++ )
-	    x[i] += ( 0 - 0.5f ) * f;			/* rand()/RAND_MAX is an integer division */
-    }
-
+    /* ---- receive: every --file of the command line as ONE batch --------------------
+     * (headers parsed, raw samples pread() into pinned memory, copied and converted on
+     * the device, demodulated chunk by chunk: mifsk_demod_files) */
     mifsk_ctx *ctx = NULL;
     rc = mifsk_ctx_create(&ctx, -1);
     if ( rc ) {
 	fprintf(stderr, "E: no MI355X available (%d); this program has no CPU receive path\n", rc);
 	return 1;
     }
-    const size_t fcap = mifsk_max_frames(&cfg, n) + 8, ecap = fcap / 8 + 64;
-    uint64_t *bits = calloc(fcap, sizeof(uint64_t));
-    mifsk_episode *eps = calloc(ecap, sizeof(mifsk_episode));
-    uint32_t nframes = 0, neps = 0, status = 0;
-    mifsk_demod_io io;
-    memset(&io, 0, sizeof(io));
-    io.d_samples = x;
-    io.stream_stride = n;
-    io.nsamples = (uint32_t)n;
-    io.nstreams = 1;
-    io.d_bits = bits;
-    io.d_nframes = &nframes;
-    io.frames_cap = fcap;
-    io.d_episodes = eps;
-    io.d_nepisodes = &neps;
-    io.episodes_cap = ecap;
-    io.d_status = &status;
-    io.flags = ring_exact ? MIFSK_IO_RING_EXACT : 0;
-    rc = mifsk_demod_batch_host(ctx, &cfg, &io);
+    mifsk_files *res = NULL;
+    rc = mifsk_demod_files(ctx, &a, (const char *const *)files, nfiles, rxnoise,
+			   flat ? 0u : MIFSK_IO_RING_EXACT, &res);
     if ( rc ) {
-	fprintf(stderr, "E: mifsk_demod_batch_host failed (%d)\n", rc);
+	fprintf(stderr, "E: mifsk_demod_files failed (%d)\n", rc);
 	return 1;
     }
-    if ( nframes > fcap ) nframes = (uint32_t)fcap;
-    if ( neps > ecap ) neps = (uint32_t)ecap;
-
     const unsigned tflags = ( print_filter ? MIFSK_TEXT_PRINT_FILTER : 0 ) | ( quiet ? MIFSK_TEXT_QUIET : 0 );
-    size_t out_len = 0, err_len = 0;
-    size_t out_cap = 64 + 320 * (size_t)( nframes ? nframes : 1 ), err_cap = 256 + 512 * (size_t)( neps ? neps : 1 );
-    char *out = malloc(out_cap), *err = malloc(err_cap);
-    rc = mifsk_stream_text(&cfg, bits, nframes, eps, neps, tflags, out, out_cap, &out_len,
-			   err, err_cap, &err_len);
-    if ( rc && rc != -ENOSPC )
-	return 1;
-    fwrite(err, 1, err_len < err_cap ? err_len : err_cap, stderr);
-    fwrite(out, 1, out_len < out_cap ? out_len : out_cap, stdout);
+    int failed = 0;
+    for ( int i = 0; i < nfiles; i++ ) {
+	const mifsk_file_result *fr = mifsk_files_get(res, i);
+	if ( nfiles > 1 && !quiet )
+	    fprintf(stderr, "### FILE %s\n", files[i]);
+	if ( fr->error ) {
+	    if ( fr->error == -EINVAL || fr->error == -ENOTSUP )
+		fprintf(stderr, "E: %s: not a mono PCM16 / float32 WAV file (%d)\n", files[i], fr->error);
+	    else
+		fprintf(stderr, "E: %s: %s\n", files[i], strerror(-fr->error));
+	    failed = 1;
+	    continue;
+	}
+	if ( fr->status & ( MIFSK_STREAM_ABORTED | MIFSK_STREAM_FRAMES_TRUNCATED | MIFSK_STREAM_EPISODES_TRUNCATED ) ) {
+	    fprintf(stderr, "E: %s: receive loop %s (status %u)\n", files[i],
+		    fr->status & MIFSK_STREAM_ABORTED ? "aborted" : "ran out of output room", fr->status);
+	    failed = 1;
+	}
+	size_t out_len = 0, err_len = 0;
+	const size_t out_cap = 64 + 320 * (size_t)( fr->nframes ? fr->nframes : 1 );
+	const size_t err_cap = 256 + 512 * (size_t)( fr->nepisodes ? fr->nepisodes : 1 );
+	char *out = malloc(out_cap), *err = malloc(err_cap);
+	rc = mifsk_stream_text(fr->cfg, fr->bits, fr->nframes, fr->episodes, fr->nepisodes, tflags,
+			       out, out_cap, &out_len, err, err_cap, &err_len);
+	if ( rc && rc != -ENOSPC ) {
+	    failed = 1;
+	} else {
+	    fwrite(err, 1, err_len < err_cap ? err_len : err_cap, stderr);
+	    fwrite(out, 1, out_len < out_cap ? out_len : out_cap, stdout);
+	    fflush(stdout);
+	}
+	free(out);
+	free(err);
+    }
+    if ( stats && !quiet ) {
+	const mifsk_host_stats *st = mifsk_files_stats(res);
+	fprintf(stderr, "### BATCH files=%u chunks=%u h2d=%.1f MB in %.3f s (%.2f GB/s, staging %.3f s)\n",
+		st->streams, st->chunks, st->bytes_h2d / 1e6, st->seconds_total,
+		st->seconds_total > 0 ? st->bytes_h2d / st->seconds_total / 1e9 : 0.0, st->seconds_staging);
+    }
+    mifsk_files_free(res);
     mifsk_ctx_destroy(ctx);
-    return 0;
+    return failed;
 }

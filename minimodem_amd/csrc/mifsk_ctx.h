@@ -1,0 +1,61 @@
+// mifsk_ctx.h -- the device context as the host-side sources of libmifsk.so share it
+// (mifsk_capi.cpp owns it; mifsk_hostpipe.cpp adds the host-memory pipeline's state).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <mutex>
+#include <vector>
+
+#include "mifsk.h"
+#include "mifsk_device.h"
+
+namespace mifsk {
+struct HostWork;
+void host_work_destroy( HostWork *w );		// (mifsk_hostpipe.cpp)
+}
+
+using mifsk::DevCfg;
+
+struct TwKey {
+    unsigned fftsize, b_mark, b_space, bit_nsamples;
+    bool operator==( const TwKey &o ) const
+    {
+	return fftsize == o.fftsize && b_mark == o.b_mark && b_space == o.b_space
+	    && bit_nsamples == o.bit_nsamples;
+    }
+};
+
+struct TwEntry {
+    TwKey	key;
+    double	*d_tw;
+};
+
+// device-resident copies of the kernel configuration, one per distinct config
+struct CfgEntry {
+    DevCfg	host;
+    DevCfg	*dev;
+};
+
+struct mifsk_ctx {
+    int			device;
+    int			ncu;		// compute units (occupancy planning)
+    char		name[256];
+    std::mutex		lock;
+    std::vector<TwEntry>	tables;
+    std::vector<CfgEntry>	configs;
+    // spectrum table for fsk_detect_carrier
+    unsigned		cs_fftsize;
+    double		*d_cs;
+    // the host-memory pipeline's streams, events and pinned staging (mifsk_hostpipe.cpp)
+    mifsk::HostWork	*host = nullptr;
+};
+
+#define HIP_OK(call)	do { hipError_t e_ = (call); if ( e_ != hipSuccess ) { \
+	fprintf(stderr, "mifsk: %s failed: %s\n", #call, hipGetErrorString(e_)); \
+	return -EIO; } } while (0)
+
+
+// -EINVAL for a configuration the kernels cannot take (mifsk_capi.cpp)
+int mifsk_check_cfg( const mifsk_rx_config *cfg );

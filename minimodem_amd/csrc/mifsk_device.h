@@ -41,6 +41,10 @@ struct DevCfg {
     // F (n_bits - 1) + 1 distinct windows
     uint32_t	lat_grid;
     uint32_t	b_mark;			// the plan's mark band (episodes report it)
+    // closed form of the four zig-zag scans of the receive loop (fsk.c:477-484; ZigZag in
+    // mifsk_devlib.h): up / down candidate counts of [0] coarse without carrier, [1] coarse with
+    // carrier, [2] fine without, [3] fine with (minimodem.c:1236-1263,1366)
+    uint32_t	zz_up[4], zz_down[4];
     uint32_t	bit_offset[MIFSK_MAX_FRAME_BITS];	// fsk.c:204
     // expect strings as bit masks, [0]=data [1]=sync: bit k of req_mask is set
     // when bit k of the frame is required ('0'/'1'), req_val holds its value

@@ -23,6 +23,24 @@ constexpr int W_CAP = 448;	// bit windows per batch (LDS scratch)
 // arithmetic shared by every kernel
 // ---------------------------------------------------------------------------
 
+// A kernel's by-value arguments as they lie in the kernarg segment, re-read where
+// they are used.  The receive-loop kernels take ONE struct; what the cold ends of
+// the loop need from it (output pointers, capacities, the final counts) is loaded
+// there through this pointer -- scalar loads that hit the scalar cache -- instead
+// of sitting in (or being spilled from) scalar registers for the whole loop: the
+// compiler hoists loads of plain kernel arguments to the top of the kernel, the
+// empty asm makes each use site's loads its own.
+template <typename Args>
+struct KernArgs {
+    typedef __attribute__((address_space(4))) const Args *ptr;
+    static __device__ __forceinline__ ptr here()
+    {
+	ptr p = (ptr)__builtin_amdgcn_kernarg_segment_ptr();
+	asm volatile("" : "+s"(p));
+	return p;
+    }
+};
+
 struct FrameOut {
     float	conf;
     float	ampl;
@@ -221,6 +239,16 @@ struct ZigZag {
 	    J = U + D;
 	}
     }
+    // one of the receive loop's four scans, its counts made on the host
+    // (DevCfg::zz_up / zz_down): kind = 2 * fine + carrier
+    __device__ __forceinline__ ZigZag( const DevCfg &cfg, uint32_t kind )
+    {
+	first = cfg.try_first[kind & 1u];
+	step = ( kind & 2u ) ? cfg.try_step_fine[kind & 1u] : cfg.try_step[kind & 1u];
+	U = cfg.zz_up[kind & 3u];
+	D = cfg.zz_down[kind & 3u];
+	J = U + D;
+    }
     // i-th candidate (0-based, scan order)
     __device__ __forceinline__ uint32_t at( uint32_t i ) const
     {
@@ -234,7 +262,6 @@ struct ZigZag {
     }
 };
 
-constexpr int XCH = 8;		// samples per register chunk in the correlator
 constexpr int STAGE_VEC = 10;	// float4 per thread per staging round
 
 // rel / bit_nsamples without a hardware divide: magic = floor(2^32 / B)
@@ -320,17 +347,6 @@ __device__ __forceinline__ void store4_skewed( const DevCfg &cfg, float *slab, u
 	}
     }
 }
-
-typedef double tw8 __attribute__((ext_vector_type(8)));
-
-#define MIFSK_FMA4(X, T, I)					\
-    do {							\
-	const double xd_ = (double)(X);				\
-	mr = fma(xd_, (T)[4 * (I) + 0], mr);			\
-	mi = fma(xd_, (T)[4 * (I) + 1], mi);			\
-	sr = fma(xd_, (T)[4 * (I) + 2], sr);			\
-	si = fma(xd_, (T)[4 * (I) + 3], si);			\
-    } while (0)
 
 // Make this wave's LDS writes visible to its other lanes.  LDS operations of one
 // wave execute in order, so no hardware wait is needed; wavefront-scope fences
@@ -543,99 +559,8 @@ __device__ __forceinline__ float4 load4_unaligned( const float *__restrict__ x, 
     return make_float4(s.x, s.y, s.z, s.w);
 }
 
-// The correlation loop of the linear variant, software-pipelined over half
-// chunks: while the 16 FMAs of 4 samples issue, the twiddles (scalar cache) and
-// the samples (LDS) of the next 4 are in flight, so neither latency is exposed.
-// One asm statement with fixed registers, because a load whose result is only
-// valid after a LATER s_waitcnt cannot be expressed to the compiler: given
-// separate asm statements it is free to copy or spill the destination registers
-// in between (it did).  Same operations in the same order as MIFSK_FMA4 over
-// samples 0 .. 8 nchunks - 1; the table is zero-padded to whole chunks.
-//   s[34:35] running table pointer, s33 chunks left,
-//   s[36:67] / s[68:99] twiddles of the even / odd half chunk,
-//   v[110:113] / v[114:117] samples of the even / odd half chunk,
-//   v119 running LDS address, v[120:121] the sample as a double.
-typedef __attribute__((address_space(3))) const float lds_cfloat;
-
-#define MIFSK_ASM_FMA4(X, S0, S1, S2, S3)			\
-	"v_cvt_f64_f32_e32 v[120:121], " X "\n\t"		\
-	"v_fmac_f64_e32 %[mr], " S0 ", v[120:121]\n\t"		\
-	"v_fmac_f64_e32 %[mi], " S1 ", v[120:121]\n\t"		\
-	"v_fmac_f64_e32 %[sr], " S2 ", v[120:121]\n\t"		\
-	"v_fmac_f64_e32 %[si], " S3 ", v[120:121]\n\t"
-
-__device__ __forceinline__ void correlate_linear_asm( const double *tw, const float *p,
-	uint32_t nchunks, double &mr, double &mi, double &sr, double &si )
-{
-    const uint32_t tw_lo = (uint32_t)(uintptr_t)tw;
-    const uint32_t tw_hi = (uint32_t)( (uintptr_t)tw >> 32 );
-    const uint32_t addr = (uint32_t)(uintptr_t)(lds_cfloat *)p;
-    asm volatile(
-	"s_mov_b32 s34, %[tlo]\n\t"
-	"s_mov_b32 s35, %[thi]\n\t"
-	"s_mov_b32 s33, %[nch]\n\t"
-	"v_mov_b32_e32 v119, %[addr]\n\t"
-	"s_load_dwordx16 s[36:51], s[34:35], 0x0\n\t"
-	"s_load_dwordx16 s[52:67], s[34:35], 0x40\n\t"
-	"ds_read_b128 v[110:113], v119\n\t"
-	"1:\n\t"
-	"s_waitcnt lgkmcnt(0)\n\t"
-	"s_load_dwordx16 s[68:83], s[34:35], 0x80\n\t"
-	"s_load_dwordx16 s[84:99], s[34:35], 0xc0\n\t"
-	"ds_read_b128 v[114:117], v119 offset:16\n\t"
-	MIFSK_ASM_FMA4("v110", "s[36:37]", "s[38:39]", "s[40:41]", "s[42:43]")
-	MIFSK_ASM_FMA4("v111", "s[44:45]", "s[46:47]", "s[48:49]", "s[50:51]")
-	MIFSK_ASM_FMA4("v112", "s[52:53]", "s[54:55]", "s[56:57]", "s[58:59]")
-	MIFSK_ASM_FMA4("v113", "s[60:61]", "s[62:63]", "s[64:65]", "s[66:67]")
-	"s_add_u32 s34, s34, 0x100\n\t"
-	"s_addc_u32 s35, s35, 0\n\t"
-	"v_add_u32_e32 v119, 32, v119\n\t"
-	"s_sub_u32 s33, s33, 1\n\t"
-	"s_waitcnt lgkmcnt(0)\n\t"
-	"s_cmp_eq_u32 s33, 0\n\t"
-	"s_cbranch_scc1 2f\n\t"
-	"s_load_dwordx16 s[36:51], s[34:35], 0x0\n\t"
-	"s_load_dwordx16 s[52:67], s[34:35], 0x40\n\t"
-	"ds_read_b128 v[110:113], v119\n\t"
-	"2:\n\t"
-	MIFSK_ASM_FMA4("v114", "s[68:69]", "s[70:71]", "s[72:73]", "s[74:75]")
-	MIFSK_ASM_FMA4("v115", "s[76:77]", "s[78:79]", "s[80:81]", "s[82:83]")
-	MIFSK_ASM_FMA4("v116", "s[84:85]", "s[86:87]", "s[88:89]", "s[90:91]")
-	MIFSK_ASM_FMA4("v117", "s[92:93]", "s[94:95]", "s[96:97]", "s[98:99]")
-	"s_cmp_lg_u32 s33, 0\n\t"
-	"s_cbranch_scc1 1b\n\t"
-	: [mr] "+v"(mr), [mi] "+v"(mi), [sr] "+v"(sr), [si] "+v"(si)
-	: [tlo] "s"(tw_lo), [thi] "s"(tw_hi), [nch] "s"(nchunks), [addr] "v"(addr)
-	: "memory", "scc",
-	  "s33", "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45",
-	  "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58",
-	  "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71",
-	  "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84",
-	  "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97",
-	  "s98", "s99",
-	  "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v119", "v120", "v121");
-}
-
-__device__ __forceinline__ void twiddle_fetch_ro( const double *t, tw8 &a, tw8 &b, tw8 &c, tw8 &d )
-{
-    // no "memory" clobber: that would make hipcc drain vmcnt, i.e. wait for the
-    // next chunk's samples right after asking for them
-    asm volatile("s_load_dwordx16 %0, %4, 0x0\n\t"
-		 "s_load_dwordx16 %1, %4, 0x40\n\t"
-		 "s_load_dwordx16 %2, %4, 0x80\n\t"
-		 "s_load_dwordx16 %3, %4, 0xc0"
-		 : "=&s"(a), "=&s"(b), "=&s"(c), "=&s"(d)
-		 : "s"(t));
-}
-
-__device__ __forceinline__ void twiddle_wait_ro()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)");
-    __builtin_amdgcn_sched_barrier(0);
-}
-
 // ---------------------------------------------------------------------------
-// Correlators with the twiddles in VECTOR registers (mifsk_wave.hip).
+// Correlators with the twiddles in VECTOR registers (both engines).
 //
 // One lane = one bit window, so at any step every lane needs the SAME twiddle
 // w[n].  Instead of streaming the table through the scalar cache (s_load into
@@ -820,6 +745,39 @@ __device__ __forceinline__ void corr_lds_stream( const double *__restrict__ tw, 
 	G = Gn;
 	s0 = n0; s1 = n1; s2 = n2; s3 = n3;
     }
+    const uint32_t left = ( nq - 4u * ( ng - 1u ) ) * 4u;	// samples in the last group
+    dpp_settle();
+    if ( left >= 16u )
+	group_bcast(acc, G, s0, s1, s2, s3);
+    else
+	group_bcast_tail(acc, G, s0, s1, s2, s3, left);
+}
+
+// The same with only the TABLE a group ahead: the window's own samples are read
+// from LDS when their group is due (16 registers instead of 32).  For waves
+// that also hold a staging round in registers (the workgroup engine's workers)
+// at four waves per SIMD, where the other waves cover the LDS latency.
+__device__ __forceinline__ void corr_lds_stream_lean( const double *__restrict__ tw, const float *p,
+	uint32_t nq, uint32_t lane, double (&acc)[4] )
+{
+    const uint32_t ng = ( nq + 3u ) >> 2;
+    TwGroup G = tw_group_load(tw, 0, lane);
+    for ( uint32_t g = 0; g + 1u < ng; g++ ) {		// (nothing left in flight at the end)
+	const TwGroup Gn = tw_group_load(tw, g + 1u, lane);
+	const float *pc = p + 16u * g;
+	const float4 s0 = *reinterpret_cast<const float4 *>(pc);
+	const float4 s1 = *reinterpret_cast<const float4 *>(pc + 4);
+	const float4 s2 = *reinterpret_cast<const float4 *>(pc + 8);
+	const float4 s3 = *reinterpret_cast<const float4 *>(pc + 12);
+	dpp_settle();
+	group_bcast(acc, G, s0, s1, s2, s3);
+	G = Gn;
+    }
+    const float *pc = p + 16u * ( ng - 1u );
+    const float4 s0 = *reinterpret_cast<const float4 *>(pc);
+    const float4 s1 = *reinterpret_cast<const float4 *>(pc + 4);
+    const float4 s2 = *reinterpret_cast<const float4 *>(pc + 8);
+    const float4 s3 = *reinterpret_cast<const float4 *>(pc + 12);
     const uint32_t left = ( nq - 4u * ( ng - 1u ) ) * 4u;	// samples in the last group
     dpp_settle();
     if ( left >= 16u )

@@ -127,30 +127,40 @@ extern "C" int mifsk_ingest_rxnoise_f32( mifsk_ctx *ctx, float *d_samples, size_
 static uint32_t rd32( const unsigned char *p ) { return p[0] | p[1] << 8 | p[2] << 16 | (uint32_t)p[3] << 24; }
 static uint32_t rd16( const unsigned char *p ) { return p[0] | p[1] << 8; }
 
+// `have` bytes of the file are in memory at `file`, the file itself is `len` bytes long
+// (the batched loader reads headers only)
+namespace mifsk { int wav_parse_sized( const void *file, size_t have, size_t len, mifsk_wav_info *info ); }
+
 extern "C" int mifsk_wav_parse( const void *file, size_t len, mifsk_wav_info *info )
 {
-    if ( !file || !info )
+    return mifsk::wav_parse_sized(file, len, len, info);
+}
+
+int mifsk::wav_parse_sized( const void *file, size_t have, size_t len, mifsk_wav_info *info )
+{
+    if ( !file || !info || have > len )
 	return -EINVAL;
     memset(info, 0, sizeof *info);
     const unsigned char *p = (const unsigned char *)file;
-    if ( len < 12 || memcmp(p, "RIFF", 4) != 0 || memcmp(p + 8, "WAVE", 4) != 0 )
+    if ( have < 12 || memcmp(p, "RIFF", 4) != 0 || memcmp(p + 8, "WAVE", 4) != 0 )
 	return -EINVAL;
     bool have_fmt = false;
     unsigned block_align = 0;
     size_t pos = 12;
-    while ( pos + 8 <= len ) {
+    while ( pos + 8 <= have ) {
 	const uint32_t sz = rd32(p + pos + 4);
 	const unsigned char *body = p + pos + 8;
-	const size_t avail = len - ( pos + 8 );
+	const size_t avail = len - ( pos + 8 );		// of the file
+	const size_t here = have - ( pos + 8 );		// of it, in memory
 	if ( memcmp(p + pos, "fmt ", 4) == 0 ) {
-	    if ( sz < 16 || avail < 16 )
+	    if ( sz < 16 || here < 16 )
 		return -EINVAL;
 	    unsigned tag = rd16(body);
 	    info->channels = rd16(body + 2);
 	    info->sample_rate = rd32(body + 4);
 	    block_align = rd16(body + 12);
 	    info->bits_per_sample = rd16(body + 14);
-	    if ( tag == 0xFFFE && sz >= 26 && avail >= 26 )	// WAVE_FORMAT_EXTENSIBLE: sub-format GUID
+	    if ( tag == 0xFFFE && sz >= 26 && here >= 26 )	// WAVE_FORMAT_EXTENSIBLE: sub-format GUID
 		tag = rd16(body + 24);
 	    if ( tag == 1 && info->bits_per_sample == 16 )
 		info->is_float = 0;

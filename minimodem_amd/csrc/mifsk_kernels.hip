@@ -189,6 +189,9 @@ struct StreamLds {
     // master needs a SCAN): the workers poll it and go straight to the barrier
     uint32_t	abort;
     uint32_t	pad[3];		// (which entries are valid is the master's private state)
+    // work counters (MIFSK_CNT_*), bumped by lane 0 of the master: kept out of the
+    // scalar registers, which the loop state needs
+    uint32_t	cnt[MIFSK_NCOUNTERS];
     // Two command slots used alternately: the one published before barrier
     // number n is slot n & 1, so a slot is rewritten only after every wave has
     // passed another barrier and is done reading it.
@@ -335,8 +338,6 @@ struct Master {
     // is the frame whose first try sits at lat_anchor + e * lock_advance
     uint32_t		lat_n, lat_anchor;
     uint32_t		hit_base = 0xFFFFFFFFu;	// cursor of the last scan a lattice frame answered
-    // work counters (written out only when the caller asked for them)
-    uint32_t		n_batches = 0, n_stages = 0, n_hits = 0, n_positions = 0, n_lattice = 0;
     uint32_t		cyc_par = 0, cyc_conf = 0, cyc_wait = 0, cyc_scan_wait = 0;
 
     __device__ __forceinline__ Master( const DevCfg &c, const double *t, const float *xs,
@@ -355,6 +356,13 @@ struct Master {
 	    const uint32_t r = lane / lat_round, fr = lane - r * lat_round;
 	    conf_idx = r * ( lat_round * ( cfg.n_bits - 1u ) + 1u ) + fr * ( cfg.n_bits - 1u );
 	}
+    }
+
+    // (ds_add_u32 without return: fire and forget, the serial wave never waits for it)
+    __device__ __forceinline__ void bump( uint32_t which, uint32_t by = 1u ) const
+    {
+	if ( lane == 0 )
+	    (void)__hip_atomic_fetch_add(&lds->cnt[which], by, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
 
     // index of the scored lattice frame whose first try is at p, or ~0u
@@ -425,7 +433,7 @@ struct Master {
 	seq++;
 	const uint32_t t_c = MIFSK_CLOCK();
 	cyc_wait += t_c - t_w;
-	n_lattice++;
+	bump(MIFSK_CNT_LATTICE_BATCHES);
 	if ( lane < frames ) {
 	    const FrameOut fo = frame_confidence_any(&lds->mags[buf][conf_idx],
 						     cfg.req_mask[0], cfg.req_val[0], cfg.n_bits);
@@ -463,7 +471,7 @@ struct Master {
 	    // what this search reads and no more.
 	    const uint32_t need = ( hi - lo + 7u ) & ~3u;
 	    slab_hi = lo + ( ( kind == 0u && lat_batch && need < slab_cap ) ? need : slab_cap );
-	    n_stages++;
+	    bump(MIFSK_CNT_STAGES);
 	}
 	StreamLds::Cmd *c = next_cmd();
 	if ( lane == 0 ) {
@@ -475,8 +483,8 @@ struct Master {
 	if ( inflight && lane == 0 )	// command number seq - 1 is the batch in flight
 	    *(volatile uint32_t *)&lds->abort = seq;
 	inflight = false;		// the barrier below also retires any batch in flight
-	n_batches++;
-	n_positions += nq;
+	bump(MIFSK_CNT_BATCHES);
+	bump(MIFSK_CNT_POSITIONS, nq);
 	const uint32_t t_par = MIFSK_CLOCK();
 	lds_barrier();			// command (and c_pos[]) published
 	seq++;
@@ -572,7 +580,7 @@ struct Master {
 	f.conf = 0.0f; f.ampl = 0.0f; f.bits = 0;
 	if ( lane < zz.J - 1u )
 	    f = frame_confidence_any(&sm[lane * nb], cfg.req_mask[0], cfg.req_val[0], nb);
-	n_positions += zz.J - 1u;
+	bump(MIFSK_CNT_POSITIONS, zz.J - 1u);
 	// fsk.c:492-501 in scan order, candidate 0 first; the limit of this scan
 	// is INFINITY (minimodem.c:1367)
 	r = c0;
@@ -620,7 +628,7 @@ struct Master {
 		    r.ampl = lds->c_ampl[hit];
 		    r.bits = lds->c_bits[hit];
 		    r.start = first;
-		    n_hits++;
+		    bump(MIFSK_CNT_CACHE_HITS);
 		    hit_base = base;		// (candidate 0 of a rescan at this cursor is this frame)
 		    return r;
 		}
@@ -674,6 +682,19 @@ struct Master {
 };
 
 
+// everything demod_kernel is launched with: one struct, so that its layout in the
+// kernarg segment is this struct's (KernArgs in mifsk_devlib.h)
+struct DemodArgs {
+    const DevCfg	*cfgp;
+    const double	*tw;
+    mifsk_demod_io	io;
+    uint32_t		slab_cap, lat_frames, lat_rounds, region_floats, region_cap, lat_mode;
+};
+
+// where stream s writes its results.  Made once: the serial loop is latency-bound,
+// and a scalar kept in (or spilled to a VGPR lane from) a register costs a cycle where a
+// reload from the kernarg segment costs a scalar-cache round trip per block of frames
+// (measured: 0.45 -> 0.52 ms on configs[1] with the pointers re-made at every use)
 struct StreamOut {
     uint8_t		*bytes;
     uint64_t		*bits;
@@ -694,6 +715,7 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
     uint32_t N = io.d_nsamples ? io.d_nsamples[s] : io.nsamples;
     if ( io.nstreams > 1 && (size_t)N > io.stream_stride )
 	N = (uint32_t)io.stream_stride;		// never trust a length beyond the row
+
     StreamOut o;
     o.fcap = io.frames_cap;
     o.ecap = io.episodes_cap;
@@ -722,17 +744,14 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
     uint32_t base = base0 < N ? base0 : N;	// absolute index of samplebuf[0]
     uint32_t n_out_frames = 0, n_out_bytes = 0, n_out_eps = 0, ep_first = 0;
     uint32_t status = 0;
-    uint32_t n_iter = 0, n_bulk = 0, n_refine = 0;
+
     uint32_t cyc_bulk = 0, cyc_general = 0, cyc_restart = 0, cyc_s1 = 0, cyc_s2 = 0, cyc_dpp = 0;
     const uint32_t t_start = MIFSK_CLOCK();
 #ifdef MIFSK_PROFILE
     const uint32_t t_wall0 = (uint32_t)wall_clock64();
 #endif
 
-    const ZigZag zc0(cfg.try_first[0], cfg.try_max[0], cfg.try_step[0]);
-    const ZigZag zc1(cfg.try_first[1], cfg.try_max[1], cfg.try_step[1]);
-    const ZigZag zf0(cfg.try_first[0], cfg.try_max[0], cfg.try_step_fine[0]);
-    const ZigZag zf1(cfg.try_first[1], cfg.try_max[1], cfg.try_step_fine[1]);
+    const ZigZag zc0(cfg, 0u), zc1(cfg, 1u), zf0(cfg, 2u), zf1(cfg, 3u);
 
     for (;;) {
 	// ------------------------------------------------------------------
@@ -829,6 +848,7 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 			suppressed = cfg.do_rx_sync && db == cfg.sync_byte;
 		    }
 		    const unsigned long long keep = __ballot(mine && !suppressed);
+
 		    if ( mine ) {
 			const uint32_t fi = n_out_frames + lane;
 			if ( fi < o.fcap ) {
@@ -866,7 +886,7 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 		    carrier_nsamples += (uint64_t)n * ( fn + first - cfg.overscan );
 		    base = nb + ( n - 1u ) * la;
 		    advance = la;
-		    n_bulk += n;
+		    ctx.bump(MIFSK_CNT_BULK_FRAMES, n);
 		    progressed = true;
 		}
 	    } else if ( ctx.inflight && ctx.inflight_anchor == p ) {
@@ -889,7 +909,7 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 	const uint32_t avail = N - base;
 	if ( avail == 0 || avail < cfg.expect_nsamples )
 	    break;
-	n_iter++;
+	ctx.bump(MIFSK_CNT_ITERATIONS);
 	const uint32_t t_gen = MIFSK_CLOCK();
 
 	const uint32_t ci = carrier ? 1u : 0u;
@@ -898,7 +918,7 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 	const uint32_t try_first = cfg.try_first[ci];
 
 	const uint32_t t_s1 = MIFSK_CLOCK();
-	ScanResult sr = ctx.scan(base, carrier ? zc1 : zc0, try_first, cfg.search_limit,
+	ScanResult sr =ctx.scan(base, carrier ? zc1 : zc0, try_first, cfg.search_limit,
 				 carrier ? 0u : 1u);		// minimodem.c:1265-1274
 	cyc_s1 += MIFSK_CLOCK() - t_s1;
 	float confidence = sr.conf;
@@ -916,9 +936,10 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 
 	if ( confidence <= cfg.conf_threshold ) {		// minimodem.c:1292-1321
 	    if ( ++noconfidence > 20u ) {
-		if ( carrier ) {
-		    if ( t0 && o.eps && n_out_eps < o.ecap ) {
-			mifsk_episode e;
+		    if ( carrier ) {
+
+			if ( t0 && o.eps && n_out_eps < o.ecap ) {
+			    mifsk_episode e;
 			e.carrier_nsamples = carrier_nsamples;
 			e.first_frame = ep_first;
 			e.nframes = nframes_decoded;
@@ -969,7 +990,7 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 		s2 = ctx.scan(base, ci ? zf1 : zf0, try_first, INFINITY, 0u);
 	    cyc_s2 += MIFSK_CLOCK() - t_s2;
 	    flags |= MIFSK_FRAME_REFINED;
-	    n_refine++;
+	    ctx.bump(MIFSK_CNT_REFINES);
 	    if ( s2.conf > confidence ) {
 		bits = s2.bits;
 		amplitude = s2.ampl;
@@ -993,6 +1014,7 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 	    flags |= MIFSK_FRAME_SYNC;
 
 	if ( t0 ) {
+
 	    if ( n_out_frames < o.fcap ) {
 		if ( o.bits )
 		    o.bits[n_out_frames] = bits;
@@ -1037,6 +1059,7 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 	cyc_general += MIFSK_CLOCK() - t_gen;
     }
 
+
     if ( carrier ) {						// minimodem.c:1469-1474
 	if ( t0 && o.eps && n_out_eps < o.ecap ) {
 	    mifsk_episode e;
@@ -1056,22 +1079,15 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 	    status |= MIFSK_STREAM_FRAMES_TRUNCATED;
 	if ( n_out_eps > o.ecap && o.eps )
 	    status |= MIFSK_STREAM_EPISODES_TRUNCATED;
-	if ( io.d_nframes ) io.d_nframes[s] = n_out_frames;
-	if ( io.d_nbytes ) io.d_nbytes[s] = n_out_bytes;
-	if ( io.d_nepisodes ) io.d_nepisodes[s] = n_out_eps;
-	if ( io.d_status ) io.d_status[s] = status;
-	if ( io.d_counters ) {
-	    uint64_t *c = io.d_counters + (size_t)s * MIFSK_NCOUNTERS;
+	const KernArgs<DemodArgs>::ptr a = KernArgs<DemodArgs>::here();
+	if ( a->io.d_nframes ) a->io.d_nframes[s] = n_out_frames;
+	if ( a->io.d_nbytes ) a->io.d_nbytes[s] = n_out_bytes;
+	if ( a->io.d_nepisodes ) a->io.d_nepisodes[s] = n_out_eps;
+	if ( a->io.d_status ) a->io.d_status[s] = status;
+	if ( a->io.d_counters ) {
+	    uint64_t *c = a->io.d_counters + (size_t)s * MIFSK_NCOUNTERS;
 	    for ( int i = 0; i < MIFSK_NCOUNTERS; i++ )
-		c[i] = 0;
-	    c[MIFSK_CNT_ITERATIONS] = n_iter;
-	    c[MIFSK_CNT_BATCHES] = ctx.n_batches;
-	    c[MIFSK_CNT_STAGES] = ctx.n_stages;
-	    c[MIFSK_CNT_BULK_FRAMES] = n_bulk;
-	    c[MIFSK_CNT_REFINES] = n_refine;
-	    c[MIFSK_CNT_CACHE_HITS] = ctx.n_hits;
-	    c[MIFSK_CNT_POSITIONS] = ctx.n_positions;
-	    c[MIFSK_CNT_LATTICE_BATCHES] = ctx.n_lattice;
+		c[i] = lds->cnt[i];		// (event counts; the cycle totals below are profile-build only)
 	    c[MIFSK_CNT_CYC_TOTAL] = MIFSK_CLOCK() - t_start;
 	    c[MIFSK_CNT_CYC_PARALLEL] = ctx.cyc_par;
 	    c[MIFSK_CNT_CYC_WAIT] = ctx.cyc_wait;
@@ -1134,8 +1150,7 @@ __device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const 
 	const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)a1);
 	const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)a1, (int)last) + B;
 	const uint32_t a = active ? a1 : lo;
-	// + XCH: the last chunk of the last window may run past it (zero twiddles)
-	const uint32_t nvec = ( hi - lo + XCH + 3 ) >> 2;
+	const uint32_t nvec = ( hi - lo + 3 ) >> 2;
 
 	// Raw loads of one round: 64 * STAGE_VEC consecutive float4 from sample
 	// `from`, whatever the round really needs -- no per-lane bounds logic, the
@@ -1215,7 +1230,12 @@ __device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const 
 	    corr_lds_fixed_halves<NQ>(tgr, region + ( a - lo ), acc);
 	    mr = acc[0]; mi = acc[1]; sr = acc[2]; si = acc[3];
 	} else {
-	    correlate_linear_asm(tw, region + ( a - lo ), ( B + XCH - 1 ) / XCH, mr, mi, sr, si);
+	    // any bit length (B % 4 == 0): one table group per 16 samples through the
+	    // vector cache, broadcast with DPP like the resident table (the last group
+	    // is loaded whole -- the region has the slack -- and accumulated up to B)
+	    double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
+	    corr_lds_stream_lean(tw, region + ( a - lo ), B >> 2, lane, acc);
+	    mr = acc[0]; mi = acc[1]; sr = acc[2]; si = acc[3];
 	}
 	if ( active )
 	    lds->mags[buf][win_base + w] = make_float2(band_mag(mr, mi, cfg.magscalar),
@@ -1228,20 +1248,17 @@ __device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const 
 }
 
 // LATTICE, direct variant: any bit length, no LDS.  One lane per bit window as
-// everywhere; the lane streams ITS OWN window straight from global memory, 32
-// bytes (one chunk of 8 samples) per step with the next chunk already in flight,
-// while the twiddles -- the same sample index in every lane -- come through the
-// scalar cache as usual.  Lanes' windows lie a bit length apart, so a step's 64
-// loads touch 64 different 32-byte sectors; four consecutive steps use up each
-// 128-byte line, which the caches hold in between.  Nothing has to fit anywhere:
-// this is what runs RTTY (1056-sample windows), SAME (92.16) and Bell-103 (160),
-// whose windows do not fit the linear variant's regions.  Same sums in the same
-// order as every other correlator.
+// everywhere; the lane streams ITS OWN window straight from global memory, 64
+// bytes (a group of 16 samples) per step with the next group already in flight,
+// twiddles broadcast with DPP from one table group per step (corr_global_stream).
+// Nothing has to fit anywhere: what the workgroup engine runs when it is forced
+// onto modes whose windows do not fit the linear variant's regions (RTTY, SAME,
+// Bell-103) -- the library itself sends those to the wavefront engine.  Same sums
+// in the same order as every other correlator.
 
 __device__ __forceinline__ void worker_lattice_direct( const DevCfg &cfg, const double *__restrict__ tw,
 	StreamLds *lds, const StreamLds::Cmd *cmd, const float *__restrict__ x, uint32_t N,
-	uint32_t lat_frames, uint32_t wkr, uint32_t done, uint32_t win_base, uint32_t abort_tag,
-	uint32_t (&wcyc)[3] )
+	uint32_t lat_frames, uint32_t wkr, uint32_t done, uint32_t win_base, uint32_t (&wcyc)[3] )
 {
     const uint32_t t_in = MIFSK_CLOCK();
     const uint32_t lane = threadIdx.x & 63u;
@@ -1262,34 +1279,11 @@ __device__ __forceinline__ void worker_lattice_direct( const DevCfg &cfg, const 
 	const uint32_t f = udiv_magic(wc, n_bits, cfg.nbits_magic);
 	a = anchor + f * cfg.lock_advance + cfg.bit_offset[( wc - f * n_bits ) & 63u];
     }
-    const uint32_t Bpad = ( B + XCH - 1u ) & ~(uint32_t)( XCH - 1 );
-    double mr = 0.0, mi = 0.0, sr = 0.0, si = 0.0;
+    const uint32_t Bpad = ( B + 15u ) & ~15u;	// whole groups of 16 are loaded
+    double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
     if ( __all(a + Bpad <= N && a + Bpad >= a) ) {
-	// every window of the wave (padded to whole chunks) lies inside the stream
-	const float *p = x + a;
-	float4_u c0 = *reinterpret_cast<const float4_u *>(p);
-	float4_u c1 = *reinterpret_cast<const float4_u *>(p + 4);
-	for ( uint32_t n0 = 0; n0 < B; n0 += XCH ) {
-	    float4_u d0 = c0, d1 = c1;
-	    if ( n0 + XCH < B ) {		// uniform: the next chunk, in flight during this one's FMAs
-		d0 = *reinterpret_cast<const float4_u *>(p + n0 + XCH);
-		d1 = *reinterpret_cast<const float4_u *>(p + n0 + XCH + 4);
-	    }
-	    tw8 ta, tb, tc, td;
-	    twiddle_fetch_ro(tw + 4 * (size_t)n0, ta, tb, tc, td);
-	    // long windows: give the batch up between chunks when the master asks
-	    // (the LDS read rides on the wait for the twiddles)
-	    const uint32_t ab = *(volatile uint32_t *)&lds->abort;
-	    twiddle_wait_ro();
-	    if ( ab == abort_tag )
-		return;
-	    MIFSK_FMA4(c0.x, ta, 0);  MIFSK_FMA4(c0.y, ta, 1);
-	    MIFSK_FMA4(c0.z, tb, 0);  MIFSK_FMA4(c0.w, tb, 1);
-	    MIFSK_FMA4(c1.x, tc, 0);  MIFSK_FMA4(c1.y, tc, 1);
-	    MIFSK_FMA4(c1.z, td, 0);  MIFSK_FMA4(c1.w, td, 1);
-	    c0 = d0;
-	    c1 = d1;
-	}
+	// every window of the wave (padded to whole groups) lies inside the stream
+	corr_global_stream(tw, x + a, B, lane, acc);
     } else {
 	// a window reaches the end of the stream: per-sample guarded reads
 	// (samples at or beyond N are 0.0), a handful of rounds per stream
@@ -1297,15 +1291,15 @@ __device__ __forceinline__ void worker_lattice_direct( const DevCfg &cfg, const 
 	    const uint32_t idx = a + n;
 	    const double xd = (double)( ( idx < N && idx >= a ) ? x[idx] : 0.0f );
 	    const double *t = tw + 4 * (size_t)n;
-	    mr = fma(xd, t[0], mr);
-	    mi = fma(xd, t[1], mi);
-	    sr = fma(xd, t[2], sr);
-	    si = fma(xd, t[3], si);
+	    acc[0] = fma(xd, t[0], acc[0]);
+	    acc[1] = fma(xd, t[1], acc[1]);
+	    acc[2] = fma(xd, t[2], acc[2]);
+	    acc[3] = fma(xd, t[3], acc[3]);
 	}
     }
     if ( active )
-	lds->mags[cmd->buf][win_base + w] = make_float2(band_mag(mr, mi, cfg.magscalar),
-						       band_mag(sr, si, cfg.magscalar));
+	lds->mags[cmd->buf][win_base + w] = make_float2(band_mag(acc[0], acc[1], cfg.magscalar),
+						       band_mag(acc[2], acc[3], cfg.magscalar));
     wcyc[1] += MIFSK_CLOCK() - t_in;
 }
 
@@ -1380,8 +1374,7 @@ __device__ __forceinline__ void worker_main( const DevCfg *__restrict__ cfgp,
 		for ( uint32_t done = 0; done < total; done += lat_frames, win_base += wins_per_round ) {
 		    if ( *(volatile uint32_t *)&lds->abort == seq + 1u )
 			break;
-		    worker_lattice_direct(cfg, tw, lds, cmd, x, N, lat_frames, wkr, done, win_base,
-					  seq + 1u, wcyc);
+		    worker_lattice_direct(cfg, tw, lds, cmd, x, N, lat_frames, wkr, done, win_base, wcyc);
 		}
 	    }
 	}
@@ -1398,11 +1391,15 @@ __device__ __forceinline__ void worker_main( const DevCfg *__restrict__ cfgp,
 }
 
 template <bool USE_SLAB, int NQ, int NW>
-__global__ __launch_bounds__(64 * ( NW + 1 ), NW == 2 ? 3 : 4)
-void demod_kernel( const DevCfg *__restrict__ cfgp, const double *__restrict__ tw,
-	mifsk_demod_io io, uint32_t slab_cap, uint32_t lat_frames, uint32_t lat_rounds,
-	uint32_t region_floats, uint32_t region_cap, uint32_t lat_mode )
+__global__ __launch_bounds__(64 * ( NW + 1 ), 3)
+void demod_kernel( const DemodArgs args )
 {
+    const DevCfg *__restrict__ cfgp = args.cfgp;
+    const double *__restrict__ tw = args.tw;
+    const mifsk_demod_io &io = args.io;
+    const uint32_t slab_cap = args.slab_cap, lat_rounds = args.lat_rounds;
+    const uint32_t region_floats = args.region_floats, region_cap = args.region_cap, lat_mode = args.lat_mode;
+    uint32_t lat_frames = args.lat_frames;
     StreamLds *lds = reinterpret_cast<StreamLds *>(mifsk_smem);
     const uint32_t base0 = 0u;
     // the configuration lives in device memory (uniform -> scalar loads); it is
@@ -1412,6 +1409,8 @@ void demod_kernel( const DevCfg *__restrict__ cfgp, const double *__restrict__ t
 
     if ( threadIdx.x == 0 )
 	lds->abort = 0;
+    if ( threadIdx.x < MIFSK_NCOUNTERS )
+	lds->cnt[threadIdx.x] = 0;
     lds_barrier();
 
     // How far this stream's row may be over-read (in samples from its start)
@@ -1531,12 +1530,15 @@ static int launch_with_workers( const DevCfg &cfg, const DevCfg *d_cfg, const do
     uint32_t region_cap = 0;
     size_t region_floats = 0;
     if ( lat_frames && cfg.lat_linear && ordered ) {
-	// span of the widest wave: 64 windows (or all of them)
+	// span of the widest wave: 64 windows (or all of them), plus what the
+	// group-wise correlator (corr_lds_stream: whole groups of 16 samples) loads
+	// beyond the last window -- nothing in the Bell-202 instantiation, whose
+	// resident-table correlator reads the window and no more
+	const uint32_t over = ( nworkers == 2u && B == 40u ) ? 0u : ( 16u - B % 16u ) % 16u;
 	uint32_t span = 0;
 	if ( cfg.lat_grid ) {
 	    const uint32_t nwin = wins_in(lat_frames);
-	    // the chunked correlator overruns the last window only when B % XCH != 0
-	    span = ( nwin < 64u ? nwin : 64u ) * B + ( B % XCH ? XCH : 0u );
+	    span = ( nwin < 64u ? nwin : 64u ) * B + over;
 	} else {
 	    const uint32_t nwin = lat_frames * cfg.n_bits;
 	    for ( uint32_t w0 = 0; w0 < nwin; w0 += 64 ) {
@@ -1545,7 +1547,7 @@ static int launch_with_workers( const DevCfg &cfg, const DevCfg *d_cfg, const do
 		const uint32_t hi = ( wl / cfg.n_bits ) * cfg.lock_advance + cfg.bit_offset[wl % cfg.n_bits] + B;
 		span = hi - lo > span ? hi - lo : span;
 	    }
-	    span += XCH;
+	    span += over;
 	}
 	region_cap = ( span + 3 ) & ~3u;
 	region_floats = floats_for(region_cap);
@@ -1614,17 +1616,18 @@ static int launch_with_workers( const DevCfg &cfg, const DevCfg *d_cfg, const do
 		hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 	if ( e != hipSuccess )
 	    return hip_rc(e);
+	const DemodArgs a = { d_cfg, d_tw, io, slab_cap, lat_frames, lat_rounds,
+			      (uint32_t)region_floats, region_cap, lat_mode };
 	if ( bell202 )
 	    hipLaunchKernelGGL((demod_kernel<true, 10, 2>), dim3((unsigned)io.nstreams), dim3(block),
-			       lds_bytes, st, d_cfg, d_tw, io, slab_cap, lat_frames, lat_rounds,
-			       (uint32_t)region_floats, region_cap, lat_mode);
+			       lds_bytes, st, a);
 	else
 	    hipLaunchKernelGGL((demod_kernel<true, 0, 3>), dim3((unsigned)io.nstreams), dim3(block),
-			       lds_bytes, st, d_cfg, d_tw, io, slab_cap, lat_frames, lat_rounds,
-			       (uint32_t)region_floats, region_cap, lat_mode);
+			       lds_bytes, st, a);
     } else {
+	const DemodArgs a = { d_cfg, d_tw, io, 0u, 0u, 1u, 0u, 0u, (uint32_t)LAT_NONE };
 	hipLaunchKernelGGL((demod_kernel<false, 0, 3>), dim3((unsigned)io.nstreams), dim3(block),
-			   kLdsHeader + 16, st, d_cfg, d_tw, io, 0u, 0u, 1u, 0u, 0u, (uint32_t)LAT_NONE);
+			   kLdsHeader + 16, st, a);
     }
     return hip_rc(hipGetLastError());
 }

@@ -66,6 +66,19 @@ namespace mifsk {
 // (1024 streams on 256 CUs leave each wave a quarter of a CU's LDS), 4 where
 // sixteen waves share a CU.
 
+// everything demod_wave_kernel is launched with: one struct, so that its layout in
+// the kernarg segment is this struct's (KernArgs in mifsk_devlib.h)
+struct WaveArgs {
+    const DevCfg	*cfgp;
+    const double	*tw_default;
+    mifsk_demod_io	io;
+    WaveGeom		g;
+    WaveAuto		au;
+};
+
+// where stream s writes its results.  Made once (see StreamOut in mifsk_kernels.hip: the
+// serial loop is latency-bound; re-making these from the kernarg segment at every use cost
+// 12000 baud 1.29 -> 1.79 ms)
 struct WaveOut {
     uint8_t		*bytes;
     uint64_t		*bits;
@@ -160,24 +173,31 @@ struct Wave {
     // groups 0..2 of the twiddle table (entries 0..47), resident (NQ > 0): what the
     // linear LATTICE correlator needs for its bit windows of 4 NQ <= 48 samples
     TwGroup		tgr[3];
-    // counters
-    uint32_t		n_blocks, n_scans, n_positions, n_hits, n_stages;
+    // work counters (MIFSK_CNT_*): a block of LDS words bumped by lane 0 -- kept out of
+    // the scalar registers, which the loop state needs
+    uint32_t		*cnt;
     uint32_t		cyc_block, cyc_scan, cyc_stage, cyc_corr, cyc_conf;
     uint32_t		cyc_s_stage, cyc_s_corr, cyc_s_conf;
 
     __device__ __forceinline__ Wave( const DevCfg &c, const WaveGeom &gg, const double *t,
-	    const float *xs, uint32_t n, float2 *m, float *s, float *r, uint32_t safe )
+	    const float *xs, uint32_t n, float2 *m, float *s, float *r, uint32_t safe, uint32_t *counters )
 	: cfg(c), g(gg), tw(t), x(xs), N(n), mags(m), slab(s), ring(r), lane(threadIdx.x),
 	  safe_limit(safe), slab_lo(0), slab_hi(0), l_conf(0.0f), l_ampl(0.0f), l_bits(0),
 	  lat_n(0), lat_anchor(0), spec(gg.lat_fmin), run(0), cold(0), pause(0),
-	  k0_valid(false), pref_lo(0xFFFFFFFFu), n_blocks(0), n_scans(0), n_positions(0), n_hits(0), n_stages(0),
-	  cyc_block(0), cyc_scan(0), cyc_stage(0), cyc_corr(0), cyc_conf(0),
+	  k0_valid(false), pref_lo(0xFFFFFFFFu), cnt(counters), cyc_block(0), cyc_scan(0), cyc_stage(0), cyc_corr(0), cyc_conf(0),
 	  cyc_s_stage(0), cyc_s_corr(0), cyc_s_conf(0)
     {
 #pragma unroll
 	for ( int i = 0; i < SV; i++ )
 	    pbuf[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 	load_resident_twiddles();
+    }
+
+    // (ds_add_u32 without return: fire and forget, the wave never waits for it)
+    __device__ __forceinline__ void bump( uint32_t which, uint32_t by = 1u ) const
+    {
+	if ( lane == 0 )
+	    (void)__hip_atomic_fetch_add(&cnt[which], by, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
 
     // (again after --auto-carrier has rebuilt the stream's table)
@@ -370,7 +390,7 @@ struct Wave {
 	lat_anchor = A;
 	slab_lo = slab_hi = 0;			// the rounds overwrote whatever SCAN had staged
 	wave_lds_sync();
-	n_blocks++;
+	bump(MIFSK_CNT_LATTICE_BATCHES);
 	cyc_conf += MIFSK_WCLOCK() - t_cf;
 	cyc_block += MIFSK_WCLOCK() - t0;
     }
@@ -393,6 +413,7 @@ struct Wave {
     // stage [lo, lo + n) into the skewed slab whose row 0 is sample lo
     __device__ __forceinline__ void stage_slab( uint32_t base, uint32_t lo, uint32_t n )
     {
+
 	const uint32_t org4 = lo & ~3u;
 	const uint32_t head = lo - org4;
 	const uint32_t nvec = ( n + head + 3 ) >> 2;
@@ -433,6 +454,7 @@ struct Wave {
     __device__ __forceinline__ void scan_correlate( uint32_t base, const ZigZag &zz, uint32_t c0,
 	    uint32_t Q, bool use_slab )
     {
+
 	const uint32_t nb = cfg.n_bits, B = cfg.bit_nsamples;
 	const uint32_t nwin = Q * nb;
 	for ( uint32_t w0 = 0; w0 < nwin; w0 += 64u ) {
@@ -496,7 +518,7 @@ struct Wave {
 		const uint32_t bhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)( l_bits >> 32 ), (int)hit);
 		k0.bits = ( (uint64_t)bhi << 32 ) | blo;
 		k0_valid = true;
-		n_hits++;
+		bump(MIFSK_CNT_CACHE_HITS);
 	    }
 	}
 	bool done = false;
@@ -543,7 +565,7 @@ struct Wave {
 		drop_prefetch();		// (the cursor left the lattice)
 		stage_slab(base, lo, take);
 		wave_lds_sync();
-		n_stages++;
+		    bump(MIFSK_CNT_STAGES);
 	    }
 	    const uint32_t ts1 = MIFSK_WCLOCK();
 	    scan_correlate(base, zz, c0, Q, use_slab);
@@ -557,8 +579,8 @@ struct Wave {
 	    cyc_s_stage += ts1 - ts0;
 	    cyc_s_corr += ts2 - ts1;
 	    cyc_s_conf += MIFSK_WCLOCK() - ts2;
-	    n_scans++;
-	    n_positions += Q;
+	    bump(MIFSK_CNT_BATCHES);
+	    bump(MIFSK_CNT_POSITIONS, Q);
 	    if ( c0 == 0u ) {			// candidate 0's own score, for a rescan at this cursor
 		k0.conf = lane_bcast(f.conf, 0);
 		k0.ampl = lane_bcast(f.ampl, 0);
@@ -606,6 +628,7 @@ __device__ __forceinline__ uint64_t lane_gather64( uint64_t v, uint32_t src )
 }
 
 extern __shared__ __attribute__((aligned(16))) unsigned char mifsk_wave_smem[];
+constexpr size_t kCntBytes = ( MIFSK_NCOUNTERS * sizeof(uint32_t) + 15u ) & ~(size_t)15;	// work counters, first in LDS
 
 // (the wide-staging instantiation runs where a wave has >= 10 KiB of LDS to
 // itself, i.e. at most 2-3 waves per SIMD: it may use 256 VGPRs)
@@ -614,16 +637,23 @@ extern __shared__ __attribute__((aligned(16))) unsigned char mifsk_wave_smem[];
 #endif
 template <int SV, int NQ>
 __global__ __launch_bounds__(64, SV >= 10 ? 2 : MIFSK_WAVE_OCC)
-void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restrict__ tw_default,
-	mifsk_demod_io io, WaveGeom g, WaveAuto au )
+void demod_wave_kernel( const WaveArgs args )
 {
+    const DevCfg *__restrict__ cfgp = args.cfgp;
+    const double *__restrict__ tw_default = args.tw_default;
+    const mifsk_demod_io &io = args.io;
+    const WaveGeom &g = args.g;
+    const WaveAuto &au = args.au;
     const DevCfg &cfg = *cfgp;
     const uint32_t s = blockIdx.x;
     const uint32_t lane = threadIdx.x;
     const bool t0 = lane == 0;
 
-    float2 *mags = reinterpret_cast<float2 *>(mifsk_wave_smem);
-    float *slab = reinterpret_cast<float *>(mifsk_wave_smem + (size_t)g.mags_cap * sizeof(float2));
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(mifsk_wave_smem);
+    float2 *mags = reinterpret_cast<float2 *>(mifsk_wave_smem + kCntBytes);
+    float *slab = reinterpret_cast<float *>(mifsk_wave_smem + kCntBytes + (size_t)g.mags_cap * sizeof(float2));
+    if ( lane < MIFSK_NCOUNTERS )
+	cnt[lane] = 0;
 
     const float *x = io.d_samples + (size_t)s * io.stream_stride;
     uint32_t N = io.d_nsamples ? io.d_nsamples[s] : io.nsamples;
@@ -651,6 +681,8 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 	tw = tw_own;
     }
 
+
+
     WaveOut o;
     o.fcap = (uint32_t)( io.frames_cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : io.frames_cap );
     o.ecap = (uint32_t)( io.episodes_cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : io.episodes_cap );
@@ -659,7 +691,7 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
     o.frames = io.d_frames ? io.d_frames + (size_t)s * io.frames_cap : nullptr;
     o.eps = io.d_episodes ? io.d_episodes + (size_t)s * io.episodes_cap : nullptr;
 
-    Wave<SV, NQ> ctx(cfg, g, tw, x, N, mags, slab, ring, safe_limit);
+    Wave<SV, NQ> ctx(cfg, g, tw, x, N, mags, slab, ring, safe_limit, cnt);
 
     // reference loop state (minimodem.c:1079-1088,1132-1133), uniform in the wave
     bool carrier = false;
@@ -680,17 +712,15 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 
     uint32_t n_out_frames = 0, n_out_bytes = 0, n_out_eps = 0, ep_first = 0, ep_b_mark = 0;
     uint32_t status = 0;
-    uint32_t n_iter = 0, n_bulk = 0, n_refine = 0, n_detect = 0;
+
     uint32_t cyc_bulk = 0, cyc_general = 0;
     const uint32_t t_start = MIFSK_WCLOCK();
 #ifdef MIFSK_PROFILE
     const uint32_t t_wall0 = (uint32_t)wall_clock64();
 #endif
 
-    const ZigZag zc0(cfg.try_first[0], cfg.try_max[0], cfg.try_step[0]);
-    const ZigZag zc1(cfg.try_first[1], cfg.try_max[1], cfg.try_step[1]);
-    const ZigZag zf0(cfg.try_first[0], cfg.try_max[0], cfg.try_step_fine[0]);
-    const ZigZag zf1(cfg.try_first[1], cfg.try_max[1], cfg.try_step_fine[1]);
+
+    const ZigZag zc0(cfg, 0u), zc1(cfg, 1u), zf0(cfg, 2u), zf1(cfg, 3u);
     const uint32_t la = cfg.lock_advance;
 
     // every pass through the loop moves the cursor forward (or ends the loop):
@@ -703,6 +733,7 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 	    status |= MIFSK_STREAM_ABORTED;
 	    break;
 	}
+
 	// ------------------------------------------------------------------
 	// Bulk acceptance of lattice frames.  While carrier is held and the
 	// cursor lands on the lattice, the reference's iteration for frame k
@@ -806,9 +837,10 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 			db = data_bits_of(cfg, fb);
 			suppressed = cfg.do_rx_sync && db == cfg.sync_byte;
 		    }
-		    const unsigned long long keep = __ballot(mine && !suppressed);
-		    if ( mine ) {
-			const uint32_t fi = n_out_frames + lane;
+			const unsigned long long keep = __ballot(mine && !suppressed);
+
+			if ( mine ) {
+			    const uint32_t fi = n_out_frames + lane;
 			if ( fi < o.fcap ) {
 			    if ( o.bits )
 				o.bits[fi] = db;
@@ -850,7 +882,7 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 		    // rp + m * half that leaves at least half a buffer beyond the cursor)
 		    while ( rp < base + half && rp < N )
 			rp += N - rp < half ? N - rp : half;
-		    n_bulk += n;
+		    ctx.bump(MIFSK_CNT_BULK_FRAMES, n);
 		    progressed = true;
 		}
 	    }
@@ -910,7 +942,7 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 	    while ( (float)i + nps <= (float)nvalid ) {		// float arithmetic, as there
 		band = wave_detect_window(x + base + i, (uint32_t)nps, au.d_cs, g.fftsize, g.nbands,
 					  g.auto_threshold);
-		n_detect++;
+		ctx.bump(22);
 		if ( band >= 0 )
 		    break;
 		i = (uint32_t)( (float)i + nps );
@@ -953,14 +985,14 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 
 	if ( nvalid < cfg.expect_nsamples )			// :1229
 	    break;
-	n_iter++;
+	ctx.bump(MIFSK_CNT_ITERATIONS);
 
 	const uint32_t ci = carrier ? 1u : 0u;
 	const uint32_t try_max = cfg.try_max[ci];
 	const uint32_t try_step = cfg.try_step[ci];
 	const uint32_t try_first = cfg.try_first[ci];
 
-	ScanResult sr = ctx.scan(base, carrier ? zc1 : zc0, try_first, cfg.search_limit,
+	ScanResult sr =ctx.scan(base, carrier ? zc1 : zc0, try_first, cfg.search_limit,
 				 carrier ? 0u : 1u, carrier);	// minimodem.c:1265-1274
 	float confidence = sr.conf;
 	float amplitude = sr.ampl;
@@ -978,8 +1010,9 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 	if ( confidence <= cfg.conf_threshold ) {		// minimodem.c:1292-1321
 	    if ( ++noconfidence > 20u ) {
 		carrier_band = -1;				// :1297
-		if ( carrier ) {
-		    if ( t0 && o.eps && n_out_eps < o.ecap ) {
+		    if ( carrier ) {
+
+			if ( t0 && o.eps && n_out_eps < o.ecap ) {
 			mifsk_episode e;
 			e.carrier_nsamples = carrier_nsamples;
 			e.first_frame = ep_first;
@@ -1023,9 +1056,9 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 	    // the data string over the no-carrier range (minimodem.c:1378)
 	    // (with the carrier held before this frame, the coarse scan above used the
 	    // same first try and the same data string: its candidate 0 is reused)
-	    ScanResult s2 = ctx.scan(base, ci ? zf1 : zf0, try_first, INFINITY, 0u, true, ci != 0u);
+	    ScanResult s2 =ctx.scan(base, ci ? zf1 : zf0, try_first, INFINITY, 0u, true, ci != 0u);
 	    flags |= MIFSK_FRAME_REFINED;
-	    n_refine++;
+	    ctx.bump(MIFSK_CNT_REFINES);
 	    if ( s2.conf > confidence ) {
 		bits = s2.bits;
 		amplitude = s2.ampl;
@@ -1049,6 +1082,7 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 	    flags |= MIFSK_FRAME_SYNC;
 
 	if ( t0 ) {
+
 	    if ( n_out_frames < o.fcap ) {
 		if ( o.bits )
 		    o.bits[n_out_frames] = bits;
@@ -1074,6 +1108,7 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 	cyc_general += MIFSK_WCLOCK() - t_gen;
     }
 
+
     if ( carrier ) {						// minimodem.c:1469-1474
 	if ( t0 && o.eps && n_out_eps < o.ecap ) {
 	    mifsk_episode e;
@@ -1093,23 +1128,16 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 	    status |= MIFSK_STREAM_FRAMES_TRUNCATED;
 	if ( n_out_eps > o.ecap && o.eps )
 	    status |= MIFSK_STREAM_EPISODES_TRUNCATED;
-	if ( io.d_nframes ) io.d_nframes[s] = n_out_frames;
-	if ( io.d_nbytes ) io.d_nbytes[s] = n_out_bytes;
-	if ( io.d_nepisodes ) io.d_nepisodes[s] = n_out_eps;
-	if ( io.d_status ) io.d_status[s] = status;
-	if ( io.d_carrier_band && g.autodetect ) io.d_carrier_band[s] = first_band;
-	if ( io.d_counters ) {
-	    uint64_t *c = io.d_counters + (size_t)s * MIFSK_NCOUNTERS;
+	const KernArgs<WaveArgs>::ptr a = KernArgs<WaveArgs>::here();
+	if ( a->io.d_nframes ) a->io.d_nframes[s] = n_out_frames;
+	if ( a->io.d_nbytes ) a->io.d_nbytes[s] = n_out_bytes;
+	if ( a->io.d_nepisodes ) a->io.d_nepisodes[s] = n_out_eps;
+	if ( a->io.d_status ) a->io.d_status[s] = status;
+	if ( a->io.d_carrier_band && a->g.autodetect ) a->io.d_carrier_band[s] = first_band;
+	if ( a->io.d_counters ) {
+	    uint64_t *c = a->io.d_counters + (size_t)s * MIFSK_NCOUNTERS;
 	    for ( int i = 0; i < MIFSK_NCOUNTERS; i++ )
-		c[i] = 0;
-	    c[MIFSK_CNT_ITERATIONS] = n_iter;
-	    c[MIFSK_CNT_BATCHES] = ctx.n_scans;
-	    c[MIFSK_CNT_STAGES] = ctx.n_stages;
-	    c[MIFSK_CNT_BULK_FRAMES] = n_bulk;
-	    c[MIFSK_CNT_REFINES] = n_refine;
-	    c[MIFSK_CNT_CACHE_HITS] = ctx.n_hits;
-	    c[MIFSK_CNT_POSITIONS] = ctx.n_positions;
-	    c[MIFSK_CNT_LATTICE_BATCHES] = ctx.n_blocks;
+		c[i] = cnt[i];			// (event counts; the cycle totals below are profile-build only)
 	    c[MIFSK_CNT_CYC_TOTAL] = MIFSK_WCLOCK() - t_start;
 	    c[MIFSK_CNT_CYC_PARALLEL] = ctx.cyc_scan;
 	    c[MIFSK_CNT_CYC_WAIT] = ctx.cyc_block;
@@ -1121,7 +1149,7 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 	    c[17] = ctx.cyc_s_stage;
 	    c[18] = ctx.cyc_s_corr;
 	    c[19] = ctx.cyc_s_conf;
-	    c[22] = n_detect;
+
 #ifdef MIFSK_PROFILE
 	    // when this stream started and ended on the chip-wide 100 MHz clock
 	    c[23] = ( wall_clock64() & 0xFFFFFFFFull ) | ( (uint64_t)t_wall0 << 32 );
@@ -1233,7 +1261,7 @@ bool plan_for( const DevCfg &cfg, const WaveHostArgs &ha, int sv, size_t budget,
 		g.lat_mode = LAT_DIRECT;	// (that instantiation has no staged rounds)
 	    sf = TILE_FLOATS;
 	}
-	const size_t total = (size_t)g.mags_cap * sizeof(float2) + sf * 4u + 16u;
+	const size_t total = kCntBytes + (size_t)g.mags_cap * sizeof(float2) + sf * 4u + 16u;
 	if ( total <= budget ) {
 	    g.slab_floats = (uint32_t)sf;
 	    g.slab_cap = 0;
@@ -1351,6 +1379,7 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
 	return 0;
     }
     hipStream_t st = (hipStream_t)stream;
+    const WaveArgs wa = { d_cfg, d_tw, io, g, au };
 #define MIFSK_WAVE_LAUNCH(SV_, NQ_)										\
     do {													\
 	const void *fn = reinterpret_cast<const void *>(&demod_wave_kernel<SV_, NQ_>);				\
@@ -1358,7 +1387,7 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
 		!= hipSuccess )											\
 	    return -5;												\
 	hipLaunchKernelGGL((demod_wave_kernel<SV_, NQ_>), dim3((unsigned)io.nstreams), dim3(64),		\
-			   plan.lds_bytes, st, d_cfg, d_tw, io, g, au);						\
+				   plan.lds_bytes, st, wa);						\
     } while (0)
     if ( g.tiled ) {
 	MIFSK_WAVE_LAUNCH(10, kTiled);				// RTTY and slower

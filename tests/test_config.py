@@ -79,7 +79,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in _lib.EXPORTS:
         assert hasattr(lib, name), name
-    assert lib.mifsk_abi_version() == 3
+    assert lib.mifsk_abi_version() == 4
 
 
 def test_struct_layouts_match_between_bindings():

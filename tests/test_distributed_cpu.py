@@ -141,3 +141,24 @@ def test_pipelined_gather_as_in_bench():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert seen == [[(10 + step, step + 1)] for step in range(5)]
+
+
+def test_bench_spawns_its_own_ranks_when_no_launcher_is_around():
+    """`python bench.py --gpus 2` without torchrun: bench.py must start the two ranks itself
+    (torch.distributed.run on 127.0.0.1) instead of asserting on WORLD_SIZE.  MIFSK_BENCH_DRYRUN
+    runs the launch path without a GPU: rendezvous (gloo), sharding, reduce, one JSON line."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env["MIFSK_BENCH_DRYRUN"] = "1"
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["dry_run"] and d["n_gpus"] == 2 and d["total_streams"] == 2048
