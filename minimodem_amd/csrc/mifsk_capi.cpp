@@ -193,8 +193,6 @@ extern "C" int mifsk_ctx_create( mifsk_ctx **out, int device )
     ctx->device = device;
     ctx->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     std::snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
-    ctx->cs_fftsize = 0;
-    ctx->d_cs = nullptr;
     *out = ctx;
     return 0;
 }
@@ -207,8 +205,6 @@ extern "C" void mifsk_ctx_destroy( mifsk_ctx *ctx )
 	(void)hipFree(e.d_tw);
     for ( CfgEntry &e : ctx->configs )
 	(void)hipFree(e.dev);
-    if ( ctx->d_cs )
-	(void)hipFree(ctx->d_cs);
     if ( ctx->host )
 	mifsk::host_work_destroy(ctx->host);
     delete ctx;
@@ -226,6 +222,33 @@ static inline void twiddle( unsigned b, unsigned n, unsigned fftsize, double w[2
     const double ang = 2.0 * M_PI * (double)k / (double)fftsize;
     w[0] = std::cos(ang);
     w[1] = -std::sin(ang);
+}
+
+// The caches are bounded: the legacy API makes a DevCfg per window shape and a twiddle
+// table per tone pair it is re-tuned to (fsk_set_tones_by_bandshift).  Called at the top
+// of every entry point that launches, BEFORE it takes the gate: when a cache has outgrown
+// its bound, wait until no call is between lookup and launch (exclusive gate), let the
+// device finish what is running, and drop everything -- the next lookups rebuild what is
+// still in use.
+static void cache_gc( mifsk_ctx *ctx )
+{
+    constexpr size_t kMaxConfigs = 64, kMaxTables = 64, kMaxTableBytes = 64u << 20;
+    {
+	std::lock_guard<std::mutex> g(ctx->lock);
+	if ( ctx->configs.size() < kMaxConfigs && ctx->tables.size() < kMaxTables
+		&& ctx->table_bytes < kMaxTableBytes )
+	    return;
+    }
+    std::unique_lock<std::shared_mutex> x(ctx->gate);
+    std::lock_guard<std::mutex> g(ctx->lock);
+    (void)hipDeviceSynchronize();
+    for ( CfgEntry &e : ctx->configs )
+	(void)hipFree(e.dev);
+    ctx->configs.clear();
+    for ( TwEntry &e : ctx->tables )
+	(void)hipFree(e.d_tw);
+    ctx->tables.clear();
+    ctx->table_bytes = 0;
 }
 
 static int get_twiddles( mifsk_ctx *ctx, const TwKey &key, const double **d_out )
@@ -249,6 +272,7 @@ static int get_twiddles( mifsk_ctx *ctx, const TwKey &key, const double **d_out 
     HIP_OK(hipMalloc(&d, h.size() * sizeof(double)));
     HIP_OK(hipMemcpy(d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
     ctx->tables.push_back(TwEntry{key, d});
+    ctx->table_bytes += h.size() * sizeof(double);
     *d_out = d;
     return 0;
 }
@@ -261,13 +285,6 @@ static int get_devcfg( mifsk_ctx *ctx, const DevCfg &d, const DevCfg **d_out )
 	    *d_out = e.dev;
 	    return 0;
 	}
-    if ( ctx->configs.size() >= 64 ) {		// bounded cache (legacy API makes one per window shape)
-	// kernels launched on any stream may still be reading these copies
-	(void)hipDeviceSynchronize();
-	for ( CfgEntry &e : ctx->configs )
-	    (void)hipFree(e.dev);
-	ctx->configs.clear();
-    }
     DevCfg *dev = nullptr;
     HIP_OK(hipMalloc(&dev, sizeof(DevCfg)));
     HIP_OK(hipMemcpy(dev, &d, sizeof(DevCfg), hipMemcpyHostToDevice));
@@ -276,28 +293,32 @@ static int get_devcfg( mifsk_ctx *ctx, const DevCfg &d, const DevCfg **d_out )
     return 0;
 }
 
-// cos / -sin of 2 pi k / N for k < N (the spectrum table of fsk_detect_carrier)
+// cos / -sin of 2 pi k / N for k < N (the spectrum table of fsk_detect_carrier), one per
+// FFT size seen; like the other tables it is only ever freed by cache_gc()
 static int get_cs( mifsk_ctx *ctx, unsigned N, const double **d_out )
 {
     std::lock_guard<std::mutex> g(ctx->lock);
-    if ( ctx->cs_fftsize != N ) {
-	if ( ctx->d_cs )
-	    (void)hipDeviceSynchronize();	// (a kernel in flight may be reading the old table)
-	std::vector<double> h(2 * (size_t)N);
-	for ( unsigned k = 0; k < N; k++ ) {
-	    const double ang = 2.0 * M_PI * (double)k / (double)N;
-	    h[2 * (size_t)k] = std::cos(ang);
-	    h[2 * (size_t)k + 1] = -std::sin(ang);
+    for ( const TwEntry &e : ctx->tables )
+	if ( e.key == TwKey{N, 0u, 0u, 0u} ) {		// (bit_nsamples 0: never a bit table's key)
+	    *d_out = e.d_tw;
+	    return 0;
 	}
-	if ( ctx->d_cs ) (void)hipFree(ctx->d_cs);
-	ctx->d_cs = nullptr;
-	ctx->cs_fftsize = 0;
-	if ( hipMalloc(&ctx->d_cs, h.size() * sizeof(double)) != hipSuccess
-		|| hipMemcpy(ctx->d_cs, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess )
-	    return -ENOMEM;
-	ctx->cs_fftsize = N;
+    std::vector<double> h(2 * (size_t)N);
+    for ( unsigned k = 0; k < N; k++ ) {
+	const double ang = 2.0 * M_PI * (double)k / (double)N;
+	h[2 * (size_t)k] = std::cos(ang);
+	h[2 * (size_t)k + 1] = -std::sin(ang);
     }
-    *d_out = ctx->d_cs;
+    double *d = nullptr;
+    if ( hipMalloc(&d, h.size() * sizeof(double)) != hipSuccess )
+	return -ENOMEM;
+    if ( hipMemcpy(d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ) {
+	(void)hipFree(d);
+	return -ENOMEM;
+    }
+    ctx->tables.push_back(TwEntry{TwKey{N, 0u, 0u, 0u}, d});
+    ctx->table_bytes += h.size() * sizeof(double);
+    *d_out = d;
     return 0;
 }
 
@@ -320,6 +341,8 @@ extern "C" int mifsk_find_frame_batch( mifsk_ctx *ctx, const mifsk_rx_config *cf
     if ( !ctx || mifsk_check_cfg(cfg) || ( nproblems > 0 && ( !d_samples || !d_problems || !d_results ) ) )
 	return -EINVAL;
     HIP_OK(hipSetDevice(ctx->device));
+    cache_gc(ctx);
+    std::shared_lock<std::shared_mutex> gate(ctx->gate);	// lookup .. enqueue
     const double *d_tw = nullptr;
     int rc = get_twiddles(ctx, TwKey{(unsigned)cfg->fftsize, cfg->b_mark, cfg->b_space,
 				     cfg->bit_nsamples}, &d_tw);
@@ -351,7 +374,7 @@ static bool use_workgroup_engine( const mifsk_rx_config *cfg, const DevCfg &d, u
     bool workgroup = plain && !( flags & MIFSK_IO_ENGINE_WAVE )
 		  && ( ( flags & MIFSK_IO_ENGINE_WORKGROUP )
 		       || ( d.lat_linear && d.bit_nsamples >= 16u ) );
-    if ( const char *e = std::getenv("MIFSK_ENGINE") )	// diagnostic override: "workgroup" / "wave"
+    if ( const char *e = mifsk::experiment_env("MIFSK_ENGINE") )	// diagnostic override: "workgroup" / "wave"
 	if ( !( flags & ( MIFSK_IO_ENGINE_WORKGROUP | MIFSK_IO_ENGINE_WAVE ) ) )
 	    workgroup = plain && e[0] == 'w' && e[1] == 'o';
     return workgroup;
@@ -436,7 +459,13 @@ extern "C" int mifsk_demod_batch( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
 	return -EINVAL;
     if ( ( io->flags & MIFSK_IO_ENGINE_WORKGROUP ) && ( io->flags & MIFSK_IO_ENGINE_WAVE ) )
 	return -EINVAL;
+    // the workgroup engine has neither RING addressing nor the in-loop --auto-carrier
+    if ( ( io->flags & MIFSK_IO_ENGINE_WORKGROUP )
+	    && ( ( io->flags & MIFSK_IO_RING_EXACT ) || cfg->auto_carrier_threshold > 0.0f ) )
+	return -EINVAL;
     HIP_OK(hipSetDevice(ctx->device));
+    cache_gc(ctx);
+    std::shared_lock<std::shared_mutex> gate(ctx->gate);	// lookup .. enqueue
     const double *d_tw = nullptr;
     int rc = get_twiddles(ctx, TwKey{(unsigned)cfg->fftsize, cfg->b_mark, cfg->b_space,
 				     cfg->bit_nsamples}, &d_tw);
@@ -724,6 +753,8 @@ extern "C" int fsk_detect_carrier( fsk_plan *p, float *samples, unsigned int nsa
     if ( hipSetDevice(ctx->device) != hipSuccess )
 	return -1;
     const unsigned N = (unsigned)p->fftsize;
+    cache_gc(ctx);
+    std::shared_lock<std::shared_mutex> gate(ctx->gate);	// lookup .. enqueue
     const double *d_cs = nullptr;
     if ( get_cs(ctx, N, &d_cs) )
 	return -1;

@@ -6,6 +6,7 @@
 
 #include <cstdio>
 #include <mutex>
+#include <shared_mutex>
 #include <vector>
 
 #include "mifsk.h"
@@ -43,11 +44,16 @@ struct mifsk_ctx {
     int			ncu;		// compute units (occupancy planning)
     char		name[256];
     std::mutex		lock;
+    // Cached device tables (twiddles, DevCfg copies, the spectrum table) are shared by every
+    // call on the context.  A call holds `gate` shared from the moment it looks a table up
+    // until its kernels are enqueued; the collector (cache_gc, mifsk_capi.cpp) takes it
+    // exclusively and synchronises the device before it frees anything -- so nothing is freed
+    // between a lookup and a launch, or under a kernel that is still running.
+    std::shared_mutex	gate;
+    size_t		table_bytes = 0;	// twiddle tables held
     std::vector<TwEntry>	tables;
     std::vector<CfgEntry>	configs;
-    // spectrum table for fsk_detect_carrier
-    unsigned		cs_fftsize;
-    double		*d_cs;
+    // (the spectrum table of fsk_detect_carrier is a TwEntry with bit_nsamples == 0)
     // the host-memory pipeline's streams, events and pinned staging (mifsk_hostpipe.cpp)
     mifsk::HostWork	*host = nullptr;
 };

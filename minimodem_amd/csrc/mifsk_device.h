@@ -3,6 +3,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 
 #include "mifsk.h"
 
@@ -139,6 +140,15 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
 int launch_detect_carrier( const float *d_samples, unsigned nsamples,
 	const double *d_cs /* [fftsize][2] */, unsigned fftsize, unsigned nbands,
 	float *d_mags /* [nbands] */, void *stream );
+
+// Tuning overrides for experiments (MIFSK_ENGINE, MIFSK_WAVES_PER_CU, MIFSK_SV,
+// MIFSK_LDS_PAD, MIFSK_LAT_ROUNDS): honoured only when MIFSK_EXPERIMENT is set in the
+// environment, so that a stray variable cannot change what production launches.
+inline const char *experiment_env( const char *name )
+{
+    static const bool on = std::getenv("MIFSK_EXPERIMENT") != nullptr;
+    return on ? std::getenv(name) : nullptr;
+}
 
 // the HIP device a context is bound to (mifsk_capi.cpp)
 int ctx_device( const mifsk_ctx *ctx );

@@ -338,6 +338,7 @@ struct Master {
     // is the frame whose first try sits at lat_anchor + e * lock_advance
     uint32_t		lat_n, lat_anchor;
     uint32_t		hit_base = 0xFFFFFFFFu;	// cursor of the last scan a lattice frame answered
+    bool		cnt_on = false;		// work counters wanted (io.d_counters)
     uint32_t		cyc_par = 0, cyc_conf = 0, cyc_wait = 0, cyc_scan_wait = 0;
 
     __device__ __forceinline__ Master( const DevCfg &c, const double *t, const float *xs,
@@ -361,7 +362,7 @@ struct Master {
     // (ds_add_u32 without return: fire and forget, the serial wave never waits for it)
     __device__ __forceinline__ void bump( uint32_t which, uint32_t by = 1u ) const
     {
-	if ( lane == 0 )
+	if ( cnt_on && lane == 0 )
 	    (void)__hip_atomic_fetch_add(&lds->cnt[which], by, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
 
@@ -682,8 +683,13 @@ struct Master {
 };
 
 
-// everything demod_kernel is launched with: one struct, so that its layout in the
-// kernarg segment is this struct's (KernArgs in mifsk_devlib.h)
+// demod_kernel's arguments as they lie in the kernarg segment (each parameter at its natural
+// alignment, in order: exactly this struct's layout), for the cold end of the loop to re-read
+// them there (KernArgs in mifsk_devlib.h).  The kernel itself takes them as separate
+// parameters: only a `__restrict__` POINTER PARAMETER tells the compiler that nothing the
+// kernel stores can change *cfgp, and without that every configuration read inside the loop
+// is a vector load plus v_readfirstlane instead of a scalar load (measured with a struct
+// parameter: configs[1] 0.45 -> 0.54 ms, 12000 baud 1.29 -> 1.89 ms).
 struct DemodArgs {
     const DevCfg	*cfgp;
     const double	*tw;
@@ -731,6 +737,7 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
     // less than one round; DIRECT rounds stream whole windows per lane
     if ( lat_mode == LAT_LINEAR )
 	ctx.spec_floor = lat_round;
+    ctx.cnt_on = io.d_counters != nullptr;
 
     // reference loop state (minimodem.c:1079-1088,1132-1133), uniform in the wave
     bool carrier = false;
@@ -1392,14 +1399,10 @@ __device__ __forceinline__ void worker_main( const DevCfg *__restrict__ cfgp,
 
 template <bool USE_SLAB, int NQ, int NW>
 __global__ __launch_bounds__(64 * ( NW + 1 ), 3)
-void demod_kernel( const DemodArgs args )
+void demod_kernel( const DevCfg *__restrict__ cfgp, const double *__restrict__ tw,
+	mifsk_demod_io io, uint32_t slab_cap, uint32_t lat_frames, uint32_t lat_rounds,
+	uint32_t region_floats, uint32_t region_cap, uint32_t lat_mode )
 {
-    const DevCfg *__restrict__ cfgp = args.cfgp;
-    const double *__restrict__ tw = args.tw;
-    const mifsk_demod_io &io = args.io;
-    const uint32_t slab_cap = args.slab_cap, lat_rounds = args.lat_rounds;
-    const uint32_t region_floats = args.region_floats, region_cap = args.region_cap, lat_mode = args.lat_mode;
-    uint32_t lat_frames = args.lat_frames;
     StreamLds *lds = reinterpret_cast<StreamLds *>(mifsk_smem);
     const uint32_t base0 = 0u;
     // the configuration lives in device memory (uniform -> scalar loads); it is
@@ -1563,7 +1566,7 @@ static int launch_with_workers( const DevCfg &cfg, const DevCfg *d_cfg, const do
     uint32_t lat_rounds = 1;
     if ( lat_frames ) {
 	lat_rounds = 2;
-	if ( const char *e = std::getenv("MIFSK_LAT_ROUNDS") )	// experiments only
+	if ( const char *e = experiment_env("MIFSK_LAT_ROUNDS") )	// experiments only
 	    lat_rounds = (uint32_t)std::atoi(e) < 1u ? 1u : (uint32_t)std::atoi(e);
 	while ( lat_rounds > 1 && ( lat_frames * lat_rounds > P_CAP
 				    || wins_in(lat_frames) * lat_rounds > W_CAP ) )
@@ -1616,18 +1619,17 @@ static int launch_with_workers( const DevCfg &cfg, const DevCfg *d_cfg, const do
 		hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 	if ( e != hipSuccess )
 	    return hip_rc(e);
-	const DemodArgs a = { d_cfg, d_tw, io, slab_cap, lat_frames, lat_rounds,
-			      (uint32_t)region_floats, region_cap, lat_mode };
 	if ( bell202 )
 	    hipLaunchKernelGGL((demod_kernel<true, 10, 2>), dim3((unsigned)io.nstreams), dim3(block),
-			       lds_bytes, st, a);
+			       lds_bytes, st, d_cfg, d_tw, io, slab_cap, lat_frames, lat_rounds,
+			       (uint32_t)region_floats, region_cap, lat_mode);
 	else
 	    hipLaunchKernelGGL((demod_kernel<true, 0, 3>), dim3((unsigned)io.nstreams), dim3(block),
-			       lds_bytes, st, a);
+			       lds_bytes, st, d_cfg, d_tw, io, slab_cap, lat_frames, lat_rounds,
+			       (uint32_t)region_floats, region_cap, lat_mode);
     } else {
-	const DemodArgs a = { d_cfg, d_tw, io, 0u, 0u, 1u, 0u, 0u, (uint32_t)LAT_NONE };
 	hipLaunchKernelGGL((demod_kernel<false, 0, 3>), dim3((unsigned)io.nstreams), dim3(block),
-			   kLdsHeader + 16, st, a);
+			   kLdsHeader + 16, st, d_cfg, d_tw, io, 0u, 0u, 1u, 0u, 0u, (uint32_t)LAT_NONE);
     }
     return hip_rc(hipGetLastError());
 }

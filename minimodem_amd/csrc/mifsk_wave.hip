@@ -66,8 +66,10 @@ namespace mifsk {
 // (1024 streams on 256 CUs leave each wave a quarter of a CU's LDS), 4 where
 // sixteen waves share a CU.
 
-// everything demod_wave_kernel is launched with: one struct, so that its layout in
-// the kernarg segment is this struct's (KernArgs in mifsk_devlib.h)
+// demod_wave_kernel's arguments as they lie in the kernarg segment (see DemodArgs in
+// mifsk_kernels.hip: a view for the cold end of the loop; the kernel takes them as separate
+// parameters because only a __restrict__ pointer parameter keeps the configuration reads
+// scalar)
 struct WaveArgs {
     const DevCfg	*cfgp;
     const double	*tw_default;
@@ -176,15 +178,16 @@ struct Wave {
     // work counters (MIFSK_CNT_*): a block of LDS words bumped by lane 0 -- kept out of
     // the scalar registers, which the loop state needs
     uint32_t		*cnt;
+    bool		cnt_on;		// (the caller asked for them: io.d_counters)
     uint32_t		cyc_block, cyc_scan, cyc_stage, cyc_corr, cyc_conf;
     uint32_t		cyc_s_stage, cyc_s_corr, cyc_s_conf;
 
     __device__ __forceinline__ Wave( const DevCfg &c, const WaveGeom &gg, const double *t,
-	    const float *xs, uint32_t n, float2 *m, float *s, float *r, uint32_t safe, uint32_t *counters )
+	    const float *xs, uint32_t n, float2 *m, float *s, float *r,uint32_t safe, uint32_t *counters, bool counting )
 	: cfg(c), g(gg), tw(t), x(xs), N(n), mags(m), slab(s), ring(r), lane(threadIdx.x),
 	  safe_limit(safe), slab_lo(0), slab_hi(0), l_conf(0.0f), l_ampl(0.0f), l_bits(0),
 	  lat_n(0), lat_anchor(0), spec(gg.lat_fmin), run(0), cold(0), pause(0),
-	  k0_valid(false), pref_lo(0xFFFFFFFFu), cnt(counters), cyc_block(0), cyc_scan(0), cyc_stage(0), cyc_corr(0), cyc_conf(0),
+	  k0_valid(false), pref_lo(0xFFFFFFFFu),cnt(counters), cnt_on(counting), cyc_block(0), cyc_scan(0), cyc_stage(0), cyc_corr(0), cyc_conf(0),
 	  cyc_s_stage(0), cyc_s_corr(0), cyc_s_conf(0)
     {
 #pragma unroll
@@ -196,7 +199,7 @@ struct Wave {
     // (ds_add_u32 without return: fire and forget, the wave never waits for it)
     __device__ __forceinline__ void bump( uint32_t which, uint32_t by = 1u ) const
     {
-	if ( lane == 0 )
+	if ( cnt_on && lane == 0 )
 	    (void)__hip_atomic_fetch_add(&cnt[which], by, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
 
@@ -637,13 +640,9 @@ constexpr size_t kCntBytes = ( MIFSK_NCOUNTERS * sizeof(uint32_t) + 15u ) & ~(si
 #endif
 template <int SV, int NQ>
 __global__ __launch_bounds__(64, SV >= 10 ? 2 : MIFSK_WAVE_OCC)
-void demod_wave_kernel( const WaveArgs args )
+void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restrict__ tw_default,
+	mifsk_demod_io io, WaveGeom g, WaveAuto au )
 {
-    const DevCfg *__restrict__ cfgp = args.cfgp;
-    const double *__restrict__ tw_default = args.tw_default;
-    const mifsk_demod_io &io = args.io;
-    const WaveGeom &g = args.g;
-    const WaveAuto &au = args.au;
     const DevCfg &cfg = *cfgp;
     const uint32_t s = blockIdx.x;
     const uint32_t lane = threadIdx.x;
@@ -691,7 +690,7 @@ void demod_wave_kernel( const WaveArgs args )
     o.frames = io.d_frames ? io.d_frames + (size_t)s * io.frames_cap : nullptr;
     o.eps = io.d_episodes ? io.d_episodes + (size_t)s * io.episodes_cap : nullptr;
 
-    Wave<SV, NQ> ctx(cfg, g, tw, x, N, mags, slab, ring, safe_limit, cnt);
+    Wave<SV, NQ> ctx(cfg, g, tw, x, N, mags, slab, ring, safe_limit, cnt, io.d_counters != nullptr);
 
     // reference loop state (minimodem.c:1079-1088,1132-1133), uniform in the wave
     bool carrier = false;
@@ -1305,9 +1304,9 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
     if ( want < 4u ) want = 4u;
     if ( want > 16u ) want = 16u;
     int force_sv = 0;
-    if ( const char *e = std::getenv("MIFSK_WAVES_PER_CU") )	// experiments only
+    if ( const char *e = experiment_env("MIFSK_WAVES_PER_CU") )	// experiments only
 	want = (uint32_t)std::atoi(e) < 1u ? 1u : (uint32_t)std::atoi(e);
-    if ( const char *e = std::getenv("MIFSK_SV") )
+    if ( const char *e = experiment_env("MIFSK_SV") )
 	force_sv = std::atoi(e);
     Plan plan;
     bool ok = false;
@@ -1344,7 +1343,7 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
 	if ( !ok )
 	    return -12;
     }
-    if ( const char *e = std::getenv("MIFSK_LDS_PAD") )	// experiments only: limit occupancy
+    if ( const char *e = experiment_env("MIFSK_LDS_PAD") )	// experiments only: limit occupancy
 	if ( (size_t)std::atoi(e) > plan.lds_bytes )
 	    plan.lds_bytes = (size_t)std::atoi(e);
     WaveGeom &g = plan.g;
@@ -1379,7 +1378,6 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
 	return 0;
     }
     hipStream_t st = (hipStream_t)stream;
-    const WaveArgs wa = { d_cfg, d_tw, io, g, au };
 #define MIFSK_WAVE_LAUNCH(SV_, NQ_)										\
     do {													\
 	const void *fn = reinterpret_cast<const void *>(&demod_wave_kernel<SV_, NQ_>);				\
@@ -1387,7 +1385,7 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
 		!= hipSuccess )											\
 	    return -5;												\
 	hipLaunchKernelGGL((demod_wave_kernel<SV_, NQ_>), dim3((unsigned)io.nstreams), dim3(64),		\
-				   plan.lds_bytes, st, wa);						\
+				   plan.lds_bytes, st, d_cfg, d_tw, io, g, au);						\
     } while (0)
     if ( g.tiled ) {
 	MIFSK_WAVE_LAUNCH(10, kTiled);				// RTTY and slower

@@ -585,4 +585,4 @@ def test_non_finite_samples_give_the_oracles_frames(gpu, mode, variant):
             assert _same_or_both_nan(ge[field], ee[field]), (mode, i, field)
         assert int(res["status"][i]) == 0
         total += nf
-    assert total > 100
+    assert total > (40 if mode == "rtty" else 100)
