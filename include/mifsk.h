@@ -338,6 +338,52 @@ void  mifsk_host_free( void *p );
 /* upper bound on carrier episodes one stream of nsamples can yield */
 size_t mifsk_max_episodes( const mifsk_rx_config *cfg, size_t nsamples );
 
+/* ---- streams that arrive in pieces (minimodem.c:1144-1174; SURVEY 8 e) ------- */
+
+/* The receive loop's state between two calls, one per stream, in DEVICE memory;
+ * all zero = a stream that has not started.  Everything the reference carries
+ * from one pass of its loop to the next (minimodem.c:1079-1088,1132-1133,
+ * 1144-1174): the buffer arithmetic, the carrier episode's running totals, the
+ * tracker's amplitude and peak confidence, the --auto-carrier band. */
+typedef struct mifsk_stream_state {
+    uint64_t	base;		/* stream index of samplebuf[0]: the caller may drop
+				   every sample before it                         */
+    uint64_t	rp;		/* the reference's file position                  */
+    uint64_t	carrier_nsamples;
+    uint64_t	nframes_total;	/* frames emitted by all calls so far             */
+    uint32_t	advance;
+    uint32_t	flags;		/* MIFSK_STATE_*                                  */
+    float	confidence_total, amplitude_total;
+    uint32_t	nframes_decoded;
+    uint32_t	noconfidence;
+    float	track_amplitude, peak_confidence;
+    int32_t	carrier_band, first_band;
+    uint32_t	b_mark, ep_b_mark;
+    uint32_t	ep_first;
+    uint32_t	reserved[3];
+} mifsk_stream_state;
+
+#define MIFSK_STATE_STARTED	1u
+#define MIFSK_STATE_CARRIER	2u
+#define MIFSK_STATE_FINISHED	4u	/* the final slab has been processed */
+
+/* mifsk_demod_batch for streams that are longer than what is resident, or that
+ * arrive in pieces.  Row s of io->d_samples holds the samples of stream s from
+ * stream index d_origin[s] on (NULL: every row starts at index 0 -- only right
+ * for the first slab), io->d_nsamples[s] of them; d_origin[s] must not exceed
+ * d_state[s].base, i.e. the caller keeps what the loop has not passed yet and
+ * appends the new samples behind it.  With final == 0 the loop stops, and saves
+ * its state, at the first pass that could read beyond the row (it needs a whole
+ * samplebuf -- cfg->samplebuf_size samples -- beyond the cursor to be sure of
+ * seeing exactly what one call over the whole stream sees); with final != 0 the
+ * row's end is the stream's end.  Per call the outputs start at index 0 of their
+ * arrays (frames in loop order, episodes as they END); mifsk_frame.start and
+ * mifsk_episode.first_frame count from the start of the stream.  Any cut of a
+ * stream into slabs gives the frames and episodes of the single call, bit for
+ * bit.  Flat addressing, wavefront engine.  Asynchronous on `stream`. */
+int mifsk_demod_slab( mifsk_ctx *ctx, const mifsk_rx_config *cfg, const mifsk_demod_io *io,
+	mifsk_stream_state *d_state, const uint64_t *d_origin, int final, void *stream );
+
 /* ---- several GPUs (SURVEY 8 e) -------------------------------------------- */
 
 /* Streams are independent: device k of `world` owns the contiguous, balanced

@@ -688,3 +688,97 @@ def demod_files(ctx, paths, baudmode="1200", rxnoise=0.0, ring_exact=False, want
     finally:
         lib.mifsk_files_free(h)
     return out, stats
+
+
+# ---------------------------------------------------------------------------
+# streams that arrive in pieces (mifsk_demod_slab)
+# ---------------------------------------------------------------------------
+
+STATE_DTYPE = np.dtype([("base", "<u8"), ("rp", "<u8"), ("carrier_nsamples", "<u8"),
+                        ("nframes_total", "<u8"), ("advance", "<u4"), ("flags", "<u4"),
+                        ("confidence_total", "<f4"), ("amplitude_total", "<f4"),
+                        ("nframes_decoded", "<u4"), ("noconfidence", "<u4"),
+                        ("track_amplitude", "<f4"), ("peak_confidence", "<f4"),
+                        ("carrier_band", "<i4"), ("first_band", "<i4"), ("b_mark", "<u4"),
+                        ("ep_b_mark", "<u4"), ("ep_first", "<u4"), ("reserved", "<u4", (3,))])
+assert STATE_DTYPE.itemsize == 96
+STATE_FINISHED = 4
+
+
+class SlabSession:
+    """A batch of streams fed in pieces (mifsk_demod_slab; reference: the half-buffer refills of
+    src/minimodem.c:1144-1174).  feed(new_samples, final) appends each stream's new samples
+    behind what the receive loop has not passed yet, runs the loop as far as the data allows
+    and returns the frames / bytes / episodes that this made; the loop's state lives in device
+    memory between calls, the unconsumed tail of every stream on the host.  Whatever the cuts,
+    the concatenated output is the single call's, bit for bit."""
+
+    def __init__(self, ctx, cfg, nstreams, episodes_cap=16):
+        torch = _torch()
+        self.ctx, self.cfg, self.n = ctx, cfg, int(nstreams)
+        self.episodes_cap = episodes_cap
+        self.state = torch.zeros((self.n, STATE_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
+        self.origin = np.zeros(self.n, np.uint64)
+        self.tail = [np.zeros(0, np.float32) for _ in range(self.n)]
+
+    def feed(self, new, final=False, stream=None):
+        torch = _torch()
+        lib = _lib.load()
+        assert len(new) == self.n
+        for i, x in enumerate(new):
+            if x is not None and len(x):
+                self.tail[i] = np.concatenate([self.tail[i], np.asarray(x, np.float32)])
+        width = (max([len(t) for t in self.tail] + [4]) + 3) & ~3
+        host = np.zeros((self.n, width), np.float32)
+        lens = np.zeros(self.n, np.int32)
+        for i, t in enumerate(self.tail):
+            host[i, :len(t)] = t
+            lens[i] = len(t)
+        d = torch.from_numpy(host).cuda()
+        dl = torch.from_numpy(lens).cuda()
+        do = torch.from_numpy(self.origin.view(np.int64).copy()).cuda()
+        fc = max_frames(self.cfg, width)
+        dev = d.device
+        out = {"nframes": torch.zeros(self.n, dtype=torch.int32, device=dev),
+               "status": torch.zeros(self.n, dtype=torch.int32, device=dev),
+               "bytes": torch.zeros((self.n, fc), dtype=torch.uint8, device=dev),
+               "nbytes": torch.zeros(self.n, dtype=torch.int32, device=dev),
+               "bits": torch.zeros((self.n, fc), dtype=torch.int64, device=dev),
+               "frames": torch.zeros((self.n, fc, FRAME_DTYPE.itemsize), dtype=torch.uint8, device=dev),
+               "episodes": torch.zeros((self.n, self.episodes_cap, EPISODE_DTYPE.itemsize),
+                                       dtype=torch.uint8, device=dev),
+               "nepisodes": torch.zeros(self.n, dtype=torch.int32, device=dev),
+               "carrier_band": torch.full((self.n,), -1, dtype=torch.int32, device=dev)}
+        io = _lib.DemodIO()
+        io.d_samples = d.data_ptr()
+        io.stream_stride = d.stride(0) if self.n > 1 else width
+        io.d_nsamples = dl.data_ptr()
+        io.nsamples = width
+        io.nstreams = self.n
+        io.d_bytes = out["bytes"].data_ptr()
+        io.d_nbytes = out["nbytes"].data_ptr()
+        io.d_bits = out["bits"].data_ptr()
+        io.d_frames = out["frames"].data_ptr()
+        io.d_nframes = out["nframes"].data_ptr()
+        io.frames_cap = fc
+        io.d_episodes = out["episodes"].data_ptr()
+        io.d_nepisodes = out["nepisodes"].data_ptr()
+        io.episodes_cap = self.episodes_cap
+        io.d_status = out["status"].data_ptr()
+        io.d_carrier_band = out["carrier_band"].data_ptr()
+        io.flags = 0
+        rc = lib.mifsk_demod_slab(self.ctx.handle, C.byref(self.cfg), C.byref(io),
+                                  C.c_void_p(self.state.data_ptr()), C.c_void_p(do.data_ptr()),
+                                  1 if final else 0, _stream_ptr(torch, stream))
+        if rc != 0:
+            raise RuntimeError("mifsk_demod_slab failed: %d" % rc)
+        torch.cuda.synchronize()
+        res = results_to_host(out)
+        st = self.state.cpu().numpy().view(STATE_DTYPE).reshape(self.n)
+        for i in range(self.n):
+            drop = int(st["base"][i]) - int(self.origin[i])
+            if drop > 0:
+                self.tail[i] = self.tail[i][drop:]
+                self.origin[i] = st["base"][i]
+        res["state"] = st.copy()
+        return res

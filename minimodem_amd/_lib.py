@@ -202,7 +202,7 @@ EXPORTS = [
     "mifsk_tx_synthesize_batch",
     "mifsk_demod_batch_host_ex", "mifsk_host_alloc", "mifsk_host_free", "mifsk_max_episodes",
     "mifsk_demod_files", "mifsk_files_count", "mifsk_files_get", "mifsk_files_stats",
-    "mifsk_files_free",
+    "mifsk_files_free", "mifsk_demod_slab",
 ]
 
 _lib = None
@@ -309,5 +309,8 @@ def load():
     lib.mifsk_files_stats.argtypes = [C.c_void_p]
     lib.mifsk_files_free.restype = None
     lib.mifsk_files_free.argtypes = [C.c_void_p]
+    lib.mifsk_demod_slab.restype = C.c_int
+    lib.mifsk_demod_slab.argtypes = [C.c_void_p, C.POINTER(RxConfig), C.POINTER(DemodIO), C.c_void_p,
+                                     C.c_void_p, C.c_int, C.c_void_p]
     _lib = lib
     return lib

@@ -155,6 +155,10 @@ void fill_devcfg( DevCfg &d, const mifsk_rx_config &c )
 
 using mifsk::DevCfg;
 
+static_assert(sizeof(mifsk_stream_state) == 96, "mifsk_stream_state is part of the ABI");
+
+
+
 // ---------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------
@@ -385,7 +389,8 @@ static bool use_workgroup_engine( const mifsk_rx_config *cfg, const DevCfg &d, u
 // concurrent calls on different streams never share it.
 static int demod_batch_wave( mifsk_ctx *ctx, const mifsk_rx_config *cfg, const DevCfg &d,
 	const DevCfg *d_cfg, const double *d_tw, const mifsk_demod_io *io, void *stream,
-	mifsk::LaunchInfo *plan_only = nullptr )
+	mifsk::LaunchInfo *plan_only = nullptr, mifsk_stream_state *d_state = nullptr,
+	const uint64_t *d_origin = nullptr, bool final = true )
 {
     hipStream_t st = (hipStream_t)stream;
     const size_t ns = (size_t)io->nstreams;
@@ -396,6 +401,9 @@ static int demod_batch_wave( mifsk_ctx *ctx, const mifsk_rx_config *cfg, const D
     ha.fftsize = (uint32_t)cfg->fftsize;
     ha.nbands = cfg->nbands;
     ha.tw_entries = (uint32_t)mifsk::tw_entries(cfg->bit_nsamples);
+    ha.d_state = d_state;
+    ha.d_origin = d_origin;
+    ha.final = final;
     if ( plan_only ) {
 	ha.ring_exact = ( io->flags & MIFSK_IO_RING_EXACT ) != 0;
 	ha.autodetect = cfg->auto_carrier_threshold > 0.0f;
@@ -483,6 +491,37 @@ extern "C" int mifsk_demod_batch( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
     if ( !workgroup )
 	return demod_batch_wave(ctx, cfg, d, d_cfg, d_tw, io, stream);
     return mifsk::launch_demod_batch(d, d_cfg, d_tw, *io, stream);
+}
+
+// the same loop for streams that arrive in pieces: state in, state out (wavefront engine)
+extern "C" int mifsk_demod_slab( mifsk_ctx *ctx, const mifsk_rx_config *cfg, const mifsk_demod_io *io,
+	mifsk_stream_state *d_state, const uint64_t *d_origin, int final, void *stream )
+{
+    if ( !ctx || !io || !d_state || mifsk_check_cfg(cfg) )
+	return -EINVAL;
+    if ( io->nstreams < 0 || ( io->nstreams > 0 && !io->d_samples ) )
+	return -EINVAL;
+    if ( io->stream_stride % 4 != 0 || ( (uintptr_t)io->d_samples & 15u ) )
+	return -EINVAL;
+    if ( ( io->d_bytes || io->d_bits || io->d_frames ) && io->frames_cap == 0 )
+	return -EINVAL;
+    if ( io->flags & ~MIFSK_IO_ENGINE_WAVE )	// flat addressing, wavefront engine
+	return -EINVAL;
+    HIP_OK(hipSetDevice(ctx->device));
+    cache_gc(ctx);
+    std::shared_lock<std::shared_mutex> gate(ctx->gate);	// lookup .. enqueue
+    const double *d_tw = nullptr;
+    int rc = get_twiddles(ctx, TwKey{(unsigned)cfg->fftsize, cfg->b_mark, cfg->b_space,
+				     cfg->bit_nsamples}, &d_tw);
+    if ( rc )
+	return rc;
+    DevCfg d;
+    mifsk::fill_devcfg(d, *cfg);
+    const DevCfg *d_cfg = nullptr;
+    rc = get_devcfg(ctx, d, &d_cfg);
+    if ( rc )
+	return rc;
+    return demod_batch_wave(ctx, cfg, d, d_cfg, d_tw, io, stream, nullptr, d_state, d_origin, final != 0);
 }
 
 // what mifsk_demod_batch would launch for this configuration and batch size

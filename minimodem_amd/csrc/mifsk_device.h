@@ -115,6 +115,10 @@ struct WaveAuto {
     const double	*d_cs;		// [fftsize][2]: cos, -sin of 2 pi k / fftsize
     double		*d_tw_scratch;	// [nstreams][tw_entries][4]
     float		*d_ring;	// [nstreams][ring_stride], zero-initialised
+    // mifsk_demod_slab: the loop's state between calls (NULL: one call = one whole stream)
+    mifsk_stream_state	*d_state;
+    const uint64_t	*d_origin;	// stream index of each row's first sample (NULL: 0)
+    uint32_t		final;		// the rows end where the streams end
 };
 
 // what the host glue hands the launcher besides cfg / io
@@ -132,6 +136,9 @@ struct WaveHostArgs {
     uint32_t	tw_entries;
     const double *d_cs;
     double	*d_tw_scratch;
+    mifsk_stream_state *d_state;
+    const uint64_t *d_origin;
+    bool	final;
 };
 
 int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_tw,

@@ -137,6 +137,31 @@ __device__ __forceinline__ int wave_detect_window( const float *__restrict__ w, 
     return __builtin_amdgcn_readfirstlane(best_band);
 }
 
+// fsk_set_tones_by_bandshift (fsk.c:584-598) for one stream of an --auto-carrier batch: its
+// own table tw[4 n + {0,1,2,3}] = cos, -sin of 2 pi ((b n) mod N) / N for mark and space, made
+// from the cos / -sin table of the spectrum (the same values the host builds)
+__device__ __forceinline__ void wave_build_table( double *tw_own, const double *__restrict__ cs,
+	uint32_t band, uint32_t b_space, uint32_t bit_nsamples, uint32_t fftsize, uint32_t tw_entries )
+{
+    for ( uint32_t n = threadIdx.x; n < tw_entries; n += 64u ) {
+	double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0;
+	if ( n < bit_nsamples ) {
+	    const uint32_t km = ( band * n ) % fftsize;
+	    const uint32_t ks = ( b_space * n ) % fftsize;
+	    w0 = cs[2 * (size_t)km];
+	    w1 = cs[2 * (size_t)km + 1];
+	    w2 = cs[2 * (size_t)ks];
+	    w3 = cs[2 * (size_t)ks + 1];
+	}
+	double *t = tw_own + 4 * (size_t)n;
+	t[0] = w0; t[1] = w1; t[2] = w2; t[3] = w3;
+    }
+    // the table is read back through the scalar cache (and by vector loads in the
+    // tail paths): complete the stores, then drop stale lines
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    __builtin_amdgcn_s_dcache_inv();
+}
+
 // everything the kernel keeps per stream beyond the loop's scalars
 // NQ: > 0 = the resident-table correlator for windows of 4 NQ samples (linear
 // LATTICE); 0 = any bit length; kTiled = the instantiation for long windows
@@ -638,7 +663,9 @@ constexpr size_t kCntBytes = ( MIFSK_NCOUNTERS * sizeof(uint32_t) + 15u ) & ~(si
 #ifndef MIFSK_WAVE_OCC
 #define MIFSK_WAVE_OCC 4	// waves per SIMD the narrow-staging instantiations are compiled for
 #endif
-template <int SV, int NQ>
+// ST: the instantiation behind mifsk_demod_slab (state in, state out); the plain kernels do
+// not carry its code or its registers
+template <int SV, int NQ, bool ST = false>
 __global__ __launch_bounds__(64, SV >= 10 ? 2 : MIFSK_WAVE_OCC)
 void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restrict__ tw_default,
 	mifsk_demod_io io, WaveGeom g, WaveAuto au )
@@ -712,6 +739,59 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
     uint32_t n_out_frames = 0, n_out_bytes = 0, n_out_eps = 0, ep_first = 0, ep_b_mark = 0;
     uint32_t status = 0;
 
+    // mifsk_demod_slab: this row is the stream from index `origin` on, the loop resumes
+    // from the state the call before left (minimodem.c:1079-1088,1132-1133,1144-1174).
+    // Positions inside the kernel are relative to the row; what leaves it (frame starts,
+    // episode frame indices, the saved state) counts from the start of the stream.
+    const bool stateful = ST && au.d_state != nullptr;
+    const bool last_slab = !stateful || au.final != 0u;
+    uint64_t origin = 0;
+    uint32_t frame_base = 0;			// frames emitted by the calls before
+    bool resumable = true;
+    if ( stateful ) {
+	if ( au.d_origin )
+	    origin = au.d_origin[s];
+	const mifsk_stream_state st = au.d_state[s];
+	if ( st.flags & MIFSK_STATE_FINISHED ) {
+	    resumable = false;			// nothing more to do for this stream
+	} else if ( st.flags & MIFSK_STATE_STARTED ) {
+	    if ( st.base < origin || st.base - origin > (uint64_t)N || st.rp < st.base ) {
+		status |= MIFSK_STREAM_ABORTED;	// the caller dropped samples the loop still needs
+		resumable = false;
+	    } else {
+		base = (uint32_t)( st.base - origin );
+		rp = base + (uint32_t)( st.rp - st.base );
+		advance = st.advance;
+		carrier = ( st.flags & MIFSK_STATE_CARRIER ) != 0u;
+		carrier_nsamples = st.carrier_nsamples;
+		confidence_total = st.confidence_total;
+		amplitude_total = st.amplitude_total;
+		nframes_decoded = st.nframes_decoded;
+		noconfidence = st.noconfidence;
+		track_amplitude = st.track_amplitude;
+		peak_confidence = st.peak_confidence;
+		carrier_band = st.carrier_band;
+		first_band = st.first_band;
+		b_mark = st.b_mark;
+		ep_b_mark = st.ep_b_mark;
+		ep_first = st.ep_first;
+		frame_base = (uint32_t)st.nframes_total;
+		if ( g.autodetect && carrier_band >= 0 ) {	// the tones found before: this stream's table again
+		    wave_build_table(tw_own, au.d_cs, (uint32_t)carrier_band,
+				     (uint32_t)( carrier_band + g.b_shift ), cfg.bit_nsamples, g.fftsize, g.tw_entries);
+		    ctx.load_resident_twiddles();
+		}
+	    }
+	}
+    }
+    // With more of the stream to come, a pass of the loop is run only when a whole
+    // samplebuf beyond its cursor is in the row: then every refill is a full half buffer
+    // and every sample a search can read is the stream's, exactly as in a single call.
+    // Lattice frames are accepted up to that horizon (N_lat), the general path stops at it.
+    const uint32_t N_lat = last_slab ? N : ( N > g.bufsize ? N - g.bufsize : 0u );
+    bool paused = false;
+
+
     uint32_t cyc_bulk = 0, cyc_general = 0;
     const uint32_t t_start = MIFSK_WCLOCK();
 #ifdef MIFSK_PROFILE
@@ -732,6 +812,8 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 	    status |= MIFSK_STREAM_ABORTED;
 	    break;
 	}
+	if ( !resumable )
+	    break;
 
 	// ------------------------------------------------------------------
 	// Bulk acceptance of lattice frames.  While carrier is held and the
@@ -745,15 +827,15 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 	// samples_nvalid >= half the buffer >= everything a search reads: the
 	// launcher enables the lattice only for such geometries.)
 	// ------------------------------------------------------------------
-	if ( lattice_ok && carrier && advance && advance <= N - base ) {
+	if ( lattice_ok && carrier && advance && base <= N_lat && advance <= N_lat - base ) {
 	    const uint32_t t_bulk = MIFSK_WCLOCK();
 	    const uint32_t first = cfg.try_first[1];
 	    const uint32_t nb = base + advance;		// cursor of the next iteration
 	    const uint32_t p = nb + first;
 	    uint32_t e0 = ctx.lattice_lookup(p);
 	    // frames from cursor nb on that still see expect_nsamples (minimodem.c:1229)
-	    const uint32_t room = N - nb >= cfg.expect_nsamples
-				? udiv_magic(N - nb - cfg.expect_nsamples, la, cfg.la_magic) + 1u : 0u;
+	    const uint32_t room = N_lat - nb >= cfg.expect_nsamples
+				? udiv_magic(N_lat - nb - cfg.expect_nsamples, la, cfg.la_magic) + 1u : 0u;
 	    if ( e0 == ~0u && room && !ctx.pause ) {
 		uint32_t F = ctx.spec < room ? ctx.spec : room;
 		ctx.lattice_block(p, F);
@@ -846,7 +928,7 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 			    if ( o.frames ) {
 				mifsk_frame f;
 				f.bits = db;
-				f.start = (uint64_t)nb + (uint64_t)lane * la + first;
+				    f.start = origin + (uint64_t)nb + (uint64_t)lane * la + first;
 				f.confidence = cv;
 				f.amplitude = av;
 				f.flags = suppressed ? MIFSK_FRAME_SYNC : 0u;
@@ -894,6 +976,10 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 	// ------------------------------------------------------------------
 	// one iteration of the reference's loop
 	// ------------------------------------------------------------------
+	if ( !last_slab && (uint64_t)base + advance + bufsize > (uint64_t)N ) {
+	    paused = true;			// it could read beyond the row: the next slab resumes here
+	    break;
+	}
 	if ( advance == bufsize ) {				// minimodem.c:1146-1149: samples_nvalid = 0
 	    base += advance;
 	    rp = base;
@@ -955,28 +1041,11 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 	    if ( b_space < 1 || b_space >= (int)g.nbands )
 		continue;
 	    carrier_band = band;
-	    // fsk_set_tones_by_bandshift (fsk.c:584-598): this stream's own table
-	    // tw[4 n + {0,1,2,3}] = cos, -sin of 2 pi ((b n) mod N) / N for mark, space
 	    b_mark = (uint32_t)band;
 	    if ( first_band < 0 )
 		first_band = band;
-	    for ( uint32_t n = lane; n < g.tw_entries; n += 64u ) {
-		double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0;
-		if ( n < cfg.bit_nsamples ) {
-		    const uint32_t km = ( (uint32_t)band * n ) % g.fftsize;
-		    const uint32_t ks = ( (uint32_t)b_space * n ) % g.fftsize;
-		    w0 = au.d_cs[2 * (size_t)km];
-		    w1 = au.d_cs[2 * (size_t)km + 1];
-		    w2 = au.d_cs[2 * (size_t)ks];
-		    w3 = au.d_cs[2 * (size_t)ks + 1];
-		}
-		double *t = tw_own + 4 * (size_t)n;
-		t[0] = w0; t[1] = w1; t[2] = w2; t[3] = w3;
-	    }
-	    // the table is read back through the scalar cache (and by vector loads
-	    // in the tail paths): complete the stores, then drop stale lines
-	    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
-	    __builtin_amdgcn_s_dcache_inv();
+	    wave_build_table(tw_own, au.d_cs, (uint32_t)band, (uint32_t)b_space, cfg.bit_nsamples,
+			     g.fftsize, g.tw_entries);
 	    ctx.load_resident_twiddles();
 	    ctx.lat_n = 0;				// scored with the old tones
 	    ctx.slab_lo = ctx.slab_hi = 0;
@@ -1046,7 +1115,7 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 	    carrier = true;					// minimodem.c:1350-1353
 	    refine = true;
 	    flags |= MIFSK_FRAME_ACQUIRE;
-	    ep_first = n_out_frames;
+	    ep_first = frame_base + n_out_frames;
 	    ep_b_mark = b_mark;					// :1340,1344
 	}
 
@@ -1088,7 +1157,7 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 		if ( o.frames ) {
 		    mifsk_frame f;
 		    f.bits = bits;
-		    f.start = (uint64_t)base + frame_start;
+		    f.start = origin + (uint64_t)base + frame_start;
 		    f.confidence = confidence;
 		    f.amplitude = amplitude;
 		    f.flags = flags;
@@ -1108,7 +1177,30 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
     }
 
 
-    if ( carrier ) {						// minimodem.c:1469-1474
+    if ( stateful && t0 && !( status & MIFSK_STREAM_ABORTED ) && resumable ) {
+	mifsk_stream_state st;
+	st.base = origin + base;
+	st.rp = origin + rp;
+	st.carrier_nsamples = carrier_nsamples;
+	st.nframes_total = (uint64_t)frame_base + n_out_frames;
+	st.advance = advance;
+	st.flags = MIFSK_STATE_STARTED | ( carrier ? MIFSK_STATE_CARRIER : 0u )
+		 | ( paused ? 0u : MIFSK_STATE_FINISHED );
+	st.confidence_total = confidence_total;
+	st.amplitude_total = amplitude_total;
+	st.nframes_decoded = nframes_decoded;
+	st.noconfidence = noconfidence;
+	st.track_amplitude = track_amplitude;
+	st.peak_confidence = peak_confidence;
+	st.carrier_band = carrier_band;
+	st.first_band = first_band;
+	st.b_mark = b_mark;
+	st.ep_b_mark = ep_b_mark;
+	st.ep_first = ep_first;
+	st.reserved[0] = st.reserved[1] = st.reserved[2] = 0;
+	au.d_state[s] = st;
+    }
+    if ( carrier && !paused && resumable ) {			// minimodem.c:1469-1474
 	if ( t0 && o.eps && n_out_eps < o.ecap ) {
 	    mifsk_episode e;
 	    e.carrier_nsamples = carrier_nsamples;
@@ -1361,6 +1453,9 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
     au.d_cs = ha.d_cs;
     au.d_tw_scratch = ha.d_tw_scratch;
     au.d_ring = ha.d_ring;
+    au.d_state = ha.d_state;
+    au.d_origin = ha.d_origin;
+    au.final = ha.final ? 1u : 0u;
 
     // the instantiation: staging width x resident-table correlator for the bit
     // lengths that have one (linear LATTICE only)
@@ -1378,6 +1473,23 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
 	return 0;
     }
     hipStream_t st = (hipStream_t)stream;
+#define MIFSK_WAVE_LAUNCH_ST(SV_, NQ_)										\
+    do {													\
+	const void *fn = reinterpret_cast<const void *>(&demod_wave_kernel<SV_, NQ_, true>);			\
+	if ( hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes)		\
+		!= hipSuccess )											\
+	    return -5;												\
+	hipLaunchKernelGGL((demod_wave_kernel<SV_, NQ_, true>), dim3((unsigned)io.nstreams), dim3(64),		\
+			   plan.lds_bytes, st, d_cfg, d_tw, io, g, au);						\
+    } while (0)
+    if ( ha.d_state ) {
+	// mifsk_demod_slab: the instantiations with the state code, generic correlators
+	if ( g.tiled )          MIFSK_WAVE_LAUNCH_ST(10, kTiled);
+	else if ( plan.sv == 10 ) MIFSK_WAVE_LAUNCH_ST(10, 0);
+	else                    MIFSK_WAVE_LAUNCH_ST(4, 0);
+	return hipGetLastError() == hipSuccess ? 0 : -5;
+    }
+#undef MIFSK_WAVE_LAUNCH_ST
 #define MIFSK_WAVE_LAUNCH(SV_, NQ_)										\
     do {													\
 	const void *fn = reinterpret_cast<const void *>(&demod_wave_kernel<SV_, NQ_>);				\
