@@ -299,6 +299,24 @@ int mifsk_demod_plan( mifsk_ctx *ctx, const mifsk_rx_config *cfg, int nstreams,
 
 /* ---- streams that start in host memory (SURVEY 8 d "H2D-inclusive") -------- */
 
+/* How a zig-zag scan with long bit windows is evaluated (diagnostic; DESIGN.md "shared
+ * segments"): kind = 2 * fine + carrier.  valid == 0: every window is correlated by
+ * itself.  Otherwise the span the scan's windows cover is cut into nseg segments, each
+ * summed once in one of npass passes of lanes (lock-step length pass_len[p]); window w
+ * (= candidate in scan order * expect_n_bits + bit) is the sum of segments
+ * win_first[w] .. win_first[w] + win_count[w] - 1, rotated. */
+typedef struct mifsk_scan_plan {
+    uint32_t	valid, nseg, npass, nwin, span_hi;
+    uint32_t	pass_len[2], pass_min[2];
+    float	bound_c;
+    uint32_t	seg_rel[128];
+    uint16_t	seg_len[128], slot_seg[128], win_first[128], win_count[128];
+    uint32_t	p_slot[128], p_win[128];	/* the same, packed as the kernel reads it */
+    uint8_t	p_slot_seg[128];
+} mifsk_scan_plan;
+
+int mifsk_scan_plan_get( const mifsk_rx_config *cfg, int kind, mifsk_scan_plan *out );
+
 /* Same, for HOST pointers in `io` (all fields, d_ prefix notwithstanding).  The
  * batch is cut into chunks of whole streams (~64 MB of input); chunk k+1 crosses
  * PCIe on a copy stream while chunk k is demodulated and chunk k-1's results are

@@ -782,3 +782,20 @@ class SlabSession:
                 self.origin[i] = st["base"][i]
         res["state"] = st.copy()
         return res
+
+
+def scan_plan(cfg, kind):
+    """mifsk_scan_plan_get: the shared-segment plan of scan `kind` (2 * fine + carrier) as a dict
+    of numpy arrays, or None when that scan correlates every window by itself."""
+    sp = _lib.ScanPlan()
+    rc = _lib.load().mifsk_scan_plan_get(C.byref(cfg), int(kind), C.byref(sp))
+    if rc != 0:
+        raise RuntimeError("mifsk_scan_plan_get -> %d" % rc)
+    if not sp.valid:
+        return None
+    n, w = sp.nseg, sp.nwin
+    return {"nseg": n, "npass": sp.npass, "nwin": w, "span_hi": sp.span_hi,
+            "pass_len": list(sp.pass_len), "pass_min": list(sp.pass_min), "bound_c": sp.bound_c,
+            "seg_rel": np.array(sp.seg_rel[:n]), "seg_len": np.array(sp.seg_len[:n]),
+            "slot_seg": np.array(sp.slot_seg[:64 * sp.npass]),
+            "win_first": np.array(sp.win_first[:w]), "win_count": np.array(sp.win_count[:w])}

@@ -175,6 +175,15 @@ class WavInfo(C.Structure):
                 ("is_float", C.c_int), ("data_offset", C.c_size_t), ("nframes", C.c_size_t)]
 
 
+class ScanPlan(C.Structure):
+    _fields_ = [("valid", C.c_uint32), ("nseg", C.c_uint32), ("npass", C.c_uint32), ("nwin", C.c_uint32),
+                ("span_hi", C.c_uint32), ("pass_len", C.c_uint32 * 2), ("pass_min", C.c_uint32 * 2),
+                ("bound_c", C.c_float), ("seg_rel", C.c_uint32 * 128), ("seg_len", C.c_uint16 * 128),
+                ("slot_seg", C.c_uint16 * 128), ("win_first", C.c_uint16 * 128),
+                ("win_count", C.c_uint16 * 128), ("p_slot", C.c_uint32 * 128), ("p_win", C.c_uint32 * 128),
+                ("p_slot_seg", C.c_uint8 * 128)]
+
+
 class FileResult(C.Structure):
     _fields_ = [("error", C.c_int), ("info", WavInfo), ("cfg", C.POINTER(RxConfig)),
                 ("nframes", C.c_uint32), ("nbytes", C.c_uint32), ("nepisodes", C.c_uint32),
@@ -202,7 +211,7 @@ EXPORTS = [
     "mifsk_tx_synthesize_batch",
     "mifsk_demod_batch_host_ex", "mifsk_host_alloc", "mifsk_host_free", "mifsk_max_episodes",
     "mifsk_demod_files", "mifsk_files_count", "mifsk_files_get", "mifsk_files_stats",
-    "mifsk_files_free", "mifsk_demod_slab",
+    "mifsk_files_free", "mifsk_demod_slab", "mifsk_scan_plan_get",
 ]
 
 _lib = None
@@ -309,6 +318,8 @@ def load():
     lib.mifsk_files_stats.argtypes = [C.c_void_p]
     lib.mifsk_files_free.restype = None
     lib.mifsk_files_free.argtypes = [C.c_void_p]
+    lib.mifsk_scan_plan_get.restype = C.c_int
+    lib.mifsk_scan_plan_get.argtypes = [C.POINTER(RxConfig), C.c_int, C.POINTER(ScanPlan)]
     lib.mifsk_demod_slab.restype = C.c_int
     lib.mifsk_demod_slab.argtypes = [C.c_void_p, C.POINTER(RxConfig), C.POINTER(DemodIO), C.c_void_p,
                                      C.c_void_p, C.c_int, C.c_void_p]

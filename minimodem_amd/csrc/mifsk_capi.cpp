@@ -7,6 +7,7 @@
 // and context creation fails with -ENODEV when no gfx950 device is available.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cerrno>
 #include <cmath>
 #include <cstdio>
@@ -26,6 +27,133 @@
 #endif
 
 namespace mifsk {
+
+// The shared-segment plan of one zig-zag scan (SegPlan in mifsk_device.h): cut the span
+// the scan's windows cover at every window edge, drop pieces no window covers (bit
+// offsets are rounded, consecutive windows may leave a sample between them), split the
+// longest pieces until the lanes of ceil(n / 64) passes are full, hand the pieces to
+// the passes longest first.
+static void plan_segments( SegPlan &sp, const mifsk_rx_config &c, unsigned first, unsigned mx, unsigned step )
+{
+    std::memset(&sp, 0, sizeof(sp));
+    const unsigned nb = c.expect_n_bits, B = c.bit_nsamples;
+    if ( (int)first >= (int)mx || step == 0 || nb == 0 )
+	return;
+    const unsigned U = ( mx - first - 1 ) / step + 1;
+    const unsigned D = U - 1 < first / step ? U - 1 : first / step;
+    const unsigned J = U + D;
+    if ( J * nb > (unsigned)SEGW_MAX )
+	return;
+    auto at = [&]( unsigned i ) -> unsigned {
+	if ( i == 0 ) return first;
+	if ( i <= 2 * D ) return ( i & 1u ) ? first + ( ( i + 1 ) / 2 ) * step : first - ( ( i + 1 ) / 2 ) * step;
+	return first + ( i - D ) * step;
+    };
+    std::vector<unsigned> wstart(J * nb);
+    std::vector<unsigned> cuts;
+    for ( unsigned j = 0; j < J; j++ )
+	for ( unsigned k = 0; k < nb; k++ ) {
+	    const unsigned a = at(j) + c.bit_offset[k];
+	    wstart[j * nb + k] = a;
+	    cuts.push_back(a);
+	    cuts.push_back(a + B);
+	}
+    std::sort(cuts.begin(), cuts.end());
+    cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
+    struct Seg { unsigned rel, len; };
+    std::vector<Seg> segs;
+    for ( size_t i = 0; i + 1 < cuts.size(); i++ ) {
+	const unsigned lo = cuts[i], hi = cuts[i + 1];
+	bool covered = false;
+	for ( unsigned a : wstart )
+	    covered = covered || ( a <= lo && hi <= a + B );
+	if ( covered )
+	    segs.push_back(Seg{lo, hi - lo});
+    }
+    if ( segs.empty() || segs.size() > (size_t)SEG_MAX )
+	return;
+    const unsigned npass = (unsigned)( ( segs.size() + 63 ) / 64 );
+    const size_t cap = 64u * npass;
+    while ( segs.size() < cap ) {			// balance: halve the longest piece
+	size_t m = 0;
+	for ( size_t i = 1; i < segs.size(); i++ )
+	    if ( segs[i].len > segs[m].len ) m = i;
+	if ( segs[m].len < 96 )
+	    break;
+	const unsigned h = ( segs[m].len / 2 + 3 ) & ~3u;
+	const Seg tail{segs[m].rel + h, segs[m].len - h};
+	segs[m].len = h;
+	segs.insert(segs.begin() + (long)m + 1, tail);
+    }
+    // passes: longest pieces first, position order inside a pass
+    std::vector<unsigned> order(segs.size());
+    for ( size_t i = 0; i < order.size(); i++ ) order[i] = (unsigned)i;
+    std::stable_sort(order.begin(), order.end(), [&]( unsigned a, unsigned b ) { return segs[a].len > segs[b].len; });
+    sp.nseg = (unsigned)segs.size();
+    sp.npass = npass;
+    sp.nwin = J * nb;
+    for ( unsigned i = 0; i < (unsigned)SEG_MAX; i++ )
+	sp.slot_seg[i] = 0xFFFFu;
+    unsigned lmax = 0;
+    for ( unsigned pss = 0; pss < npass; pss++ ) {
+	std::vector<unsigned> mine(order.begin() + 64 * pss,
+				   order.begin() + (long)std::min<size_t>(order.size(), 64 * ( pss + 1 )));
+	std::sort(mine.begin(), mine.end());
+	sp.pass_len[pss] = 0;
+	sp.pass_min[pss] = 0xFFFFFFFFu;
+	for ( size_t l = 0; l < mine.size(); l++ ) {
+	    sp.slot_seg[64 * pss + l] = (uint16_t)mine[l];
+	    sp.pass_len[pss] = std::max(sp.pass_len[pss], segs[mine[l]].len);
+	    sp.pass_min[pss] = std::min(sp.pass_min[pss], segs[mine[l]].len);
+	}
+	lmax = std::max(lmax, sp.pass_len[pss]);
+    }
+    for ( size_t i = 0; i < segs.size(); i++ ) {
+	sp.seg_rel[i] = segs[i].rel;
+	sp.seg_len[i] = (uint16_t)segs[i].len;
+	sp.span_hi = std::max(sp.span_hi, segs[i].rel + segs[i].len);
+    }
+    unsigned cmax = 0;
+    for ( unsigned w = 0; w < sp.nwin; w++ ) {
+	unsigned f = 0, n = 0;
+	bool in = false;
+	for ( unsigned i = 0; i < sp.nseg; i++ ) {
+	    const bool inside = segs[i].rel >= wstart[w] && segs[i].rel + segs[i].len <= wstart[w] + B;
+	    if ( inside && !in ) { f = i; in = true; }
+	    if ( inside ) n++;
+	}
+	sp.win_first[w] = (uint16_t)f;
+	sp.win_count[w] = (uint16_t)n;
+	cmax = std::max(cmax, n);
+	// (its pieces are consecutive and tile it but for the uncovered samples, which no
+	// window contains: those lie between windows, never inside one)
+	unsigned total = 0;
+	for ( unsigned i = f; i < f + n; i++ ) total += segs[i].len;
+	if ( total != B )
+	    return;				// (cannot happen; leaves valid = 0)
+    }
+    // DESIGN.md "shared segments": index-order rounding (B - 1) + segment sums
+    // sqrt(2) (L - 1) + assembly 2 n + table entries' own rounding 85, in units of
+    // 2^-53 * sum |x|; rounded up generously
+    sp.bound_c = (float)( B + 1.5 * lmax + 2.0 * cmax + 128.0 );
+    // (a pass loads table group ceil(L / 16) + 3 at most; the table has ceil(B / 16) + 1)
+    if ( ( lmax + 15 ) / 16 + 3 > ( B + 15 ) / 16 )
+	return;
+    // packed copies; a plan whose numbers do not fit the fields is not used
+    if ( lmax >= 4096u || sp.span_hi >= ( 1u << 20 ) || sp.nseg > 255u )
+	return;
+    for ( unsigned i = 0; i < (unsigned)SEG_MAX; i++ ) {
+	const unsigned s = sp.slot_seg[i];
+	sp.p_slot_seg[i] = s == 0xFFFFu ? 0xFFu : (uint8_t)s;
+	sp.p_slot[i] = s == 0xFFFFu ? 0u : ( sp.seg_rel[s] | ( (uint32_t)sp.seg_len[s] << 20 ) );
+    }
+    for ( unsigned w = 0; w < sp.nwin; w++ ) {
+	if ( wstart[w] >= 65536u || sp.win_count[w] > 255u )
+	    return;
+	sp.p_win[w] = sp.win_first[w] | ( (uint32_t)sp.win_count[w] << 8 ) | ( wstart[w] << 16 );
+    }
+    sp.valid = 1;
+}
 
 void fill_devcfg( DevCfg &d, const mifsk_rx_config &c )
 {
@@ -109,6 +237,12 @@ void fill_devcfg( DevCfg &d, const mifsk_rx_config &c )
 	    d.zz_down[i] = d.zz_up[i] - 1 < f / st ? d.zz_up[i] - 1 : f / st;
 	}
     }
+    // long windows (what the wavefront engine reads through its LDS tile): the scans share
+    // their segments' partial sums
+    if ( c.bit_nsamples >= 256u && c.bit_nsamples <= 65535u )
+	for ( int i = 0; i < 4; i++ )
+	    plan_segments(d.seg[i], c, c.try_first[i & 1], c.try_max[i & 1],
+			  ( i & 2 ) ? c.try_step_fine[i & 1] : c.try_step[i & 1]);
     d.div_magic = c.bit_nsamples > 1 ? (uint32_t)( 0x100000000ULL / c.bit_nsamples ) : 0xFFFFFFFFu;
     // minimodem.c:1407 with frame_start == try_first (carrier)
     d.lock_advance = c.try_first[1] + c.frame_nsamples - c.nsamples_overscan;
@@ -491,6 +625,21 @@ extern "C" int mifsk_demod_batch( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
     if ( !workgroup )
 	return demod_batch_wave(ctx, cfg, d, d_cfg, d_tw, io, stream);
     return mifsk::launch_demod_batch(d, d_cfg, d_tw, *io, stream);
+}
+
+static_assert(sizeof(mifsk_scan_plan) == sizeof(mifsk::SegPlan), "mifsk_scan_plan mirrors SegPlan");
+
+extern "C" int mifsk_scan_plan_get( const mifsk_rx_config *cfg, int kind, mifsk_scan_plan *out )
+{
+    if ( mifsk_check_cfg(cfg) || !out || kind < 0 || kind > 3 )
+	return -EINVAL;
+    DevCfg *d = new (std::nothrow) DevCfg();
+    if ( !d )
+	return -ENOMEM;
+    mifsk::fill_devcfg(*d, *cfg);
+    std::memcpy(out, &d->seg[kind], sizeof(*out));
+    delete d;
+    return 0;
 }
 
 // the same loop for streams that arrive in pieces: state in, state out (wavefront engine)

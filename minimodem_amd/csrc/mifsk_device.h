@@ -9,6 +9,41 @@
 
 namespace mifsk {
 
+// ---------------------------------------------------------------------------
+// Shared-segment plan of one zig-zag scan with long bit windows (SCAN in the tiled
+// instantiation of the wavefront engine; DESIGN.md "shared segments").
+//
+// All windows of one fsk_find_frame -- every candidate x every bit (fsk.c:199-254,
+// 477-502) -- cover one contiguous span of the stream, and windows of neighbouring
+// candidates overlap by most of their length.  The span is cut at every window
+// edge (and long pieces once more, to balance the lanes) into SEGMENTS; each
+// segment's two-bin partial DFT, phase origin at its own start, is computed ONCE,
+// one lane per segment in at most two passes of lanes; a window is then the sum of
+// its segments' partials, each rotated by the table entry of its offset inside the
+// window.  Indices in POSITION order: a window's segments are seg[first .. first+count).
+// Made on the host (fill_devcfg), relative to the search cursor.
+// ---------------------------------------------------------------------------
+constexpr int SEG_MAX = 128;		// segments per plan (two passes of lanes)
+constexpr int SEGW_MAX = 128;		// windows per plan
+
+struct SegPlan {
+    uint32_t	valid;			// 0: this scan correlates every window by itself
+    uint32_t	nseg, npass, nwin;	// nwin = candidates x bits, w = candidate (scan order) * n_bits + bit
+    uint32_t	span_hi;		// every segment ends at or before cursor + span_hi
+    uint32_t	pass_len[2];		// longest segment of the pass (its lock-step length)
+    uint32_t	pass_min[2];		// shortest segment of the pass (groups below it need no mask)
+    float	bound_c;		// |assembled - index order| <= bound_c * 2^-53 * sum |x| over the window
+    uint32_t	seg_rel[SEG_MAX];	// segment start, relative to the cursor
+    uint16_t	seg_len[SEG_MAX];
+    uint16_t	slot_seg[SEG_MAX];	// pass * 64 + lane -> segment, 0xFFFF: idle lane
+    uint16_t	win_first[SEGW_MAX];	// window -> its first segment ...
+    uint16_t	win_count[SEGW_MAX];	// ... and how many
+    // the same, packed as the kernel reads it (one word per lane and pass / per window):
+    uint32_t	p_slot[SEG_MAX];	// pass * 64 + lane -> seg_rel (20 bits) | seg_len << 20
+    uint32_t	p_win[SEGW_MAX];	// window -> first | count << 8 | (window start rel. to the cursor) << 16
+    uint8_t	p_slot_seg[SEG_MAX];	// pass * 64 + lane -> segment, 0xFF: idle lane
+};
+
 // Everything a kernel needs, as one POD passed by value in the kernarg
 // segment (so it lands in SGPRs / the scalar cache, uniform for the launch).
 struct DevCfg {
@@ -51,6 +86,9 @@ struct DevCfg {
     // when bit k of the frame is required ('0'/'1'), req_val holds its value
     uint64_t	req_mask[2];
     uint64_t	req_val[2];
+    // shared-segment plans of the four scans (index as zz_up / zz_down); valid only for
+    // the long-window modes the tiled instantiation runs
+    SegPlan	seg[4];
 };
 
 // twiddles: tw[4*n + {0,1,2,3}] = cos_mark, -sin_mark, cos_space, -sin_space

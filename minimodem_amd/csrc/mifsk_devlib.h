@@ -226,8 +226,10 @@ struct ScanResult {
 // D valid down-positions (u = 1..D), J = U + D candidates in total.
 struct ZigZag {
     uint32_t first, step, U, D, J;
+    uint32_t id;		// which of the receive loop's four scans (2 * fine + carrier), or 4: none of them
     __device__ __forceinline__ ZigZag( uint32_t f, uint32_t mx, uint32_t s )
     {
+	id = 4u;
 	first = f;
 	step = s;
 	if ( (int)f >= (int)mx || s == 0 ) {
@@ -248,6 +250,7 @@ struct ZigZag {
 	U = cfg.zz_up[kind & 3u];
 	D = cfg.zz_down[kind & 3u];
 	J = U + D;
+	id = kind & 3u;
     }
     // i-th candidate (0-based, scan order)
     __device__ __forceinline__ uint32_t at( uint32_t i ) const
@@ -936,6 +939,32 @@ __device__ __forceinline__ void corr_global_tiled_n( const double *__restrict__ 
 #undef MIFSK_TILE_FETCH
 #undef MIFSK_TILE_WRITE
 #undef MIFSK_TILE_READ
+}
+
+// ---------------------------------------------------------------------------
+// Shared segments (SegPlan, mifsk_device.h; Wave::seg_correlate): through the same tile
+// every lane sums a SEGMENT of its own length `len` (at most the pass's lock-step length)
+// -- samples at or beyond a lane's length enter as 0.0, which leaves its sums untouched
+// -- and keeps the sum of |x| over its segment for the error bound.  One group of 16
+// samples; groups that lie below the pass's shortest segment need no mask (`whole`).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void seg_group( double (&acc)[4], float &asum, const TwGroup &G,
+	float4 s0, float4 s1, float4 s2, float4 s3, uint32_t n0, uint32_t len, bool whole )
+{
+    if ( !whole ) {
+#define MIFSK_SEG_MASK(V, J) V = ( n0 + (J) < len ) ? V : 0.0f
+	MIFSK_SEG_MASK(s0.x, 0u);  MIFSK_SEG_MASK(s0.y, 1u);  MIFSK_SEG_MASK(s0.z, 2u);  MIFSK_SEG_MASK(s0.w, 3u);
+	MIFSK_SEG_MASK(s1.x, 4u);  MIFSK_SEG_MASK(s1.y, 5u);  MIFSK_SEG_MASK(s1.z, 6u);  MIFSK_SEG_MASK(s1.w, 7u);
+	MIFSK_SEG_MASK(s2.x, 8u);  MIFSK_SEG_MASK(s2.y, 9u);  MIFSK_SEG_MASK(s2.z, 10u); MIFSK_SEG_MASK(s2.w, 11u);
+	MIFSK_SEG_MASK(s3.x, 12u); MIFSK_SEG_MASK(s3.y, 13u); MIFSK_SEG_MASK(s3.z, 14u); MIFSK_SEG_MASK(s3.w, 15u);
+#undef MIFSK_SEG_MASK
+    }
+    dpp_settle();
+    group_bcast(acc, G, s0, s1, s2, s3);
+    asum += ( ( ( fabsf(s0.x) + fabsf(s0.y) ) + ( fabsf(s0.z) + fabsf(s0.w) ) )
+	    + ( ( fabsf(s1.x) + fabsf(s1.y) ) + ( fabsf(s1.z) + fabsf(s1.w) ) ) )
+	  + ( ( ( fabsf(s2.x) + fabsf(s2.y) ) + ( fabsf(s2.z) + fabsf(s2.w) ) )
+	    + ( ( fabsf(s3.x) + fabsf(s3.y) ) + ( fabsf(s3.z) + fabsf(s3.w) ) ) );
 }
 
 //   a     absolute start of this lane's window (idle lanes: any valid window)

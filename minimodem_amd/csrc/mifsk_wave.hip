@@ -206,6 +206,8 @@ struct Wave {
     bool		cnt_on;		// (the caller asked for them: io.d_counters)
     uint32_t		cyc_block, cyc_scan, cyc_stage, cyc_corr, cyc_conf;
     uint32_t		cyc_s_stage, cyc_s_corr, cyc_s_conf;
+    uint32_t		cyc_g_pass = 0, cyc_g_asm = 0, cyc_g_redo = 0;	// shared-segment SCAN: passes, assembly, index-order repeats
+
 
     __device__ __forceinline__ Wave( const DevCfg &c, const WaveGeom &gg, const double *t,
 	    const float *xs, uint32_t n, float2 *m, float *s, float *r,uint32_t safe, uint32_t *counters, bool counting )
@@ -520,6 +522,258 @@ struct Wave {
 	}
     }
 
+    // ------------------------------------------------------------------
+    // SCAN with SHARED SEGMENTS (long windows, tiled instantiation; SegPlan in
+    // mifsk_device.h): every sample of the span the scan covers is read and
+    // summed once -- one lane per segment, phase origin at the segment's start -- and a
+    // window is assembled from its segments' partial sums, each rotated by the table
+    // entry of its offset inside the window:
+    //     X_w = sum_s  S_s * w[p_s - a_w]
+    // That is the index-order sum in another order, so it differs from it by rounding
+    // only, and by no more than  delta = bound_c * 2^-53 * sum |x|  over the window
+    // (derivation in DESIGN.md).  The reference rounds X to float (the FFT's output
+    // type): wherever  (float)(X - delta) == (float)(X + delta)  that float is the one
+    // the index-order sum gives, bit for bit, and everything downstream with it.  The few
+    // windows where it is not are summed again in index order (corr_global_tiled).
+    // Fills mags[(j - c0) * n_bits + k] for candidates j = c0 .. J-1 of `zz`.
+    // ------------------------------------------------------------------
+    // The packed plan words of the two carrier-held scans (kinds 1 and 3) are copied into LDS
+    // once per stream; the acquisition scans read theirs from the plan in device memory.
+    static constexpr uint32_t kPlanWords = 2u * SEG_MAX + SEG_MAX / 4u;	// p_slot, p_win, p_slot_seg per kind
+    __device__ __forceinline__ uint32_t *plan_cache() const
+    {
+	return reinterpret_cast<uint32_t *>(slab + TILE_FLOATS) + SEG_MAX * ( 4u * 2u + 2u );	// behind the partials
+    }
+    __device__ __forceinline__ void plan_cache_fill()
+    {
+	uint32_t *pc = plan_cache();
+	for ( uint32_t kc = 0; kc < 2u; kc++ ) {
+	    const SegPlan &sp = cfg.seg[2u * kc + 1u];
+	    uint32_t *q = pc + kc * kPlanWords;
+	    for ( uint32_t i = lane; i < (uint32_t)SEG_MAX; i += 64u ) {
+		q[i] = sp.p_slot[i];
+		q[SEG_MAX + i] = sp.p_win[i];
+	    }
+	    for ( uint32_t i = lane; i < (uint32_t)SEG_MAX / 4u; i += 64u )
+		q[2u * SEG_MAX + i] = reinterpret_cast<const uint32_t *>(sp.p_slot_seg)[i];
+	}
+	wave_lds_sync();
+    }
+
+    __device__ __forceinline__ void seg_correlate( uint32_t base, const ZigZag &zz, uint32_t c0 )
+    {
+	const uint32_t kind = zz.id & 3u;
+	const SegPlan &sp = cfg.seg[kind];
+	const uint32_t nb = cfg.n_bits, B = cfg.bit_nsamples;
+	double *partD = reinterpret_cast<double *>(slab + TILE_FLOATS);		// [SEG_MAX][4]
+	float *partA = reinterpret_cast<float *>(partD + 4 * SEG_MAX);		// [SEG_MAX]
+	uint32_t *partRel = reinterpret_cast<uint32_t *>(partA + SEG_MAX);	// [SEG_MAX]
+	const bool cached = ( kind & 1u ) != 0u && cfg.seg[1].valid && cfg.seg[3].valid;
+	const uint32_t *pc = plan_cache() + ( kind >> 1 ) * kPlanWords;
+	const uint32_t tg0 = MIFSK_WCLOCK();
+	const uint32_t np = sp.npass;
+	// this lane's segment in each pass: start | length << 20, position index (0xFF: none)
+	uint32_t sw0, sw1, si0, si1;
+	if ( cached ) {
+	    sw0 = pc[lane];
+	    sw1 = pc[64u + lane];
+	    si0 = reinterpret_cast<const uint8_t *>(pc + 2u * SEG_MAX)[lane];
+	    si1 = reinterpret_cast<const uint8_t *>(pc + 2u * SEG_MAX)[64u + lane];
+	} else {
+	    sw0 = sp.p_slot[lane];
+	    sw1 = sp.p_slot[64u + lane];
+	    si0 = sp.p_slot_seg[lane];
+	    si1 = sp.p_slot_seg[64u + lane];
+	}
+	const bool have0 = si0 != 0xFFu, have1 = np > 1u && si1 != 0xFFu;
+	// idle lanes shadow lane 0's segment (lane 0 always has one)
+	sw0 = have0 ? sw0 : (uint32_t)__builtin_amdgcn_readfirstlane((int)sw0);
+	sw1 = have1 ? sw1 : ( np > 1u ? (uint32_t)__builtin_amdgcn_readfirstlane((int)sw1) : sw0 );
+	const uint32_t rel0 = sw0 & 0xFFFFFu, len0 = sw0 >> 20, rel1 = sw1 & 0xFFFFFu, len1 = sw1 >> 20;
+	const uint32_t ng0 = ( sp.pass_len[0] + 15u ) >> 4, ng1 = np > 1u ? ( sp.pass_len[1] + 15u ) >> 4 : 0u;
+	const uint32_t ns0 = ( ng0 + 3u ) >> 2, ns1 = ( ng1 + 3u ) >> 2;
+	const uint32_t min0 = sp.pass_min[0], min1 = sp.pass_min[1];
+	{
+	    // Both passes in ONE run of tile steps: while the last step of the first pass is
+	    // summed, the first step of the second is already on its way (corr_global_tiled's
+	    // scheme -- 16 lanes fetch 64 contiguous samples of one segment, every lane reads
+	    // its own row back -- with a per-lane length, see seg_group)
+	    constexpr int NLD = 16;
+	    const uint32_t sub = lane & 15u, grp = lane >> 4;
+	    const uint32_t a0 = base + rel0, a1 = base + rel1;
+	    uint32_t off0[NLD], off1[NLD];
+#pragma unroll
+	    for ( int i = 0; i < NLD; i++ ) {
+		off0[i] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)( ( 4u * (uint32_t)i + grp ) << 2 ), (int)a0) + 4u * sub;
+		off1[i] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)( ( 4u * (uint32_t)i + grp ) << 2 ), (int)a1) + 4u * sub;
+	    }
+	    float *wr = slab + grp * TILE_ROW + 4u * sub;
+	    const float *rd = slab + lane * TILE_ROW;
+	    float4 L[NLD];
+#define MIFSK_SEGP_FETCH(USE1, S)								\
+	    _Pragma("unroll")									\
+	    for ( int i = 0; i < NLD; i++ ) {							\
+		const uint32_t o_ = ( USE1 ) ? off1[i] : off0[i];				\
+		const float4_u v = *reinterpret_cast<const float4_u *>(x + o_ + TILE_K * (S));	\
+		L[i] = make_float4(v.x, v.y, v.z, v.w);						\
+	    }
+#define MIFSK_SEGP_READ(XS, H)									\
+	    _Pragma("unroll")									\
+	    for ( int j = 0; j < 4; j++ )							\
+		XS[j] = *reinterpret_cast<const float4 *>(rd + 16 * (H) + 4 * j);
+	    MIFSK_SEGP_FETCH(false, 0u)
+	    TwGroup G = tw_group_load(tw, 0, lane);
+	    double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
+	    float asum = 0.0f;
+	    uint32_t ps = 0, ls = 0;
+	    const uint32_t total = ns0 + ( np > 1u ? ns1 : 0u );
+	    for ( uint32_t t = 0; t < total; t++ ) {
+#pragma unroll
+		for ( int i = 0; i < NLD; i++ )
+		    *reinterpret_cast<float4 *>(wr + 4u * (uint32_t)i * TILE_ROW) = L[i];
+		const bool last = ls + 1u == ( ps ? ns1 : ns0 );
+		const bool turn = last && ps + 1u < np;			// the next step opens the second pass
+		const bool use1 = turn || ps == 1u;
+		const uint32_t sn = turn ? 0u : ( last ? ls : ls + 1u );	// (the very last step is fetched twice)
+		MIFSK_SEGP_FETCH(use1, sn)
+		const uint32_t g0 = 4u * ls;
+		const uint32_t ng = ps ? ng1 : ng0, len = ps ? len1 : len0, lmin = ps ? min1 : min0;
+		float4 xa[4], xb[4];
+		MIFSK_SEGP_READ(xa, 0)
+		{
+		    const TwGroup Gn = tw_group_load(tw, g0 + 1u, lane);
+		    MIFSK_SEGP_READ(xb, 1)
+		    seg_group(acc, asum, G, xa[0], xa[1], xa[2], xa[3], 16u * g0, len, 16u * g0 + 16u <= lmin);
+		    G = Gn;
+		}
+		{
+		    const TwGroup Gn = tw_group_load(tw, g0 + 2u, lane);
+		    MIFSK_SEGP_READ(xa, 2)
+		    if ( g0 + 1u < ng )
+			seg_group(acc, asum, G, xb[0], xb[1], xb[2], xb[3], 16u * ( g0 + 1u ), len, 16u * g0 + 32u <= lmin);
+		    G = Gn;
+		}
+		{
+		    const TwGroup Gn = tw_group_load(tw, g0 + 3u, lane);
+		    MIFSK_SEGP_READ(xb, 3)
+		    if ( g0 + 2u < ng )
+			seg_group(acc, asum, G, xa[0], xa[1], xa[2], xa[3], 16u * ( g0 + 2u ), len, 16u * g0 + 48u <= lmin);
+		    G = Gn;
+		}
+		{
+		    const TwGroup Gn = tw_group_load(tw, last ? 0u : g0 + 4u, lane);
+		    if ( g0 + 3u < ng )
+			seg_group(acc, asum, G, xb[0], xb[1], xb[2], xb[3], 16u * ( g0 + 3u ), len, 16u * g0 + 64u <= lmin);
+		    G = Gn;
+		}
+		if ( last ) {
+		    // this pass's partial sums, by segment position
+		    const bool have = ps ? have1 : have0;
+		    const uint32_t si = ps ? si1 : si0;
+		    if ( have ) {
+			*reinterpret_cast<double2_a16 *>(partD + 4u * si) = double2_a16{acc[0], acc[1]};
+			*reinterpret_cast<double2_a16 *>(partD + 4u * si + 2u) = double2_a16{acc[2], acc[3]};
+			partA[si] = asum;
+			partRel[si] = ps ? rel1 : rel0;
+		    }
+		    acc[0] = acc[1] = acc[2] = acc[3] = 0.0;
+		    asum = 0.0f;
+		    ps++;
+		    ls = 0;
+		} else {
+		    ls++;
+		}
+	    }
+#undef MIFSK_SEGP_FETCH
+#undef MIFSK_SEGP_READ
+	}
+	wave_lds_sync();
+	bump(20);
+	const uint32_t tg1 = MIFSK_WCLOCK();
+	cyc_g_pass += tg1 - tg0;
+	// assemble: lane = window
+	const double dscale = (double)sp.bound_c * 1.0000153 * 1.1102230246251565e-16;	// (sum |x| is a float sum)
+	unsigned long long redo0 = 0ull, redo1 = 0ull;
+	for ( uint32_t g0 = 0; g0 < sp.nwin; g0 += 64u ) {
+	    const uint32_t w = g0 + lane;
+	    const bool active = w < sp.nwin;
+	    const uint32_t ww = active ? w : 0u;
+	    const uint32_t j = udiv_magic(ww, nb, cfg.nbits_magic), k = ww - j * nb;
+	    const uint32_t pw = cached ? pc[SEG_MAX + ww] : sp.p_win[ww];
+	    const uint32_t first = pw & 0xFFu, cnt = ( pw >> 8 ) & 0xFFu, a_rel = pw >> 16;
+	    const uint32_t cmax = wave_max_u32(cnt);
+	    double mr = 0.0, mi = 0.0, sr = 0.0, si = 0.0;
+	    float aw = 0.0f;
+	    constexpr int AU = 8;			// segments per turn, every load issued before the first use
+	    for ( uint32_t i0 = 0; i0 < cmax; i0 += (uint32_t)AU ) {
+		double2_a16 p0[AU], p1[AU], t0[AU], t1[AU];
+		float as[AU];
+#pragma unroll
+		for ( int u = 0; u < AU; u++ ) {
+		    const uint32_t i = i0 + (uint32_t)u;
+		    const uint32_t s = first + ( i < cnt ? i : 0u );
+		    p0[u] = *reinterpret_cast<const double2_a16 *>(partD + 4u * s);
+		    p1[u] = *reinterpret_cast<const double2_a16 *>(partD + 4u * s + 2u);
+		    as[u] = partA[s];
+		    const uint32_t d = partRel[s] - a_rel;		// offset of the segment inside the window
+		    const double *t = tw + 4 * (size_t)d;
+		    t0[u] = *reinterpret_cast<const double2_a16 *>(t);
+		    t1[u] = *reinterpret_cast<const double2_a16 *>(t + 2);
+		}
+#pragma unroll
+		for ( int u = 0; u < AU; u++ ) {
+		    const bool in = i0 + (uint32_t)u < cnt;
+		    const double Sr = in ? p0[u].x : 0.0, Si = in ? p0[u].y : 0.0;
+		    const double Tr = in ? p1[u].x : 0.0, Ti = in ? p1[u].y : 0.0;
+		    // (Sr + i Si) (c + i m),  (c, m) = (cos, -sin) of the offset
+		    mr = fma(Sr, t0[u].x, mr);  mr = fma(-Si, t0[u].y, mr);
+		    mi = fma(Sr, t0[u].y, mi);  mi = fma(Si, t0[u].x, mi);
+		    sr = fma(Tr, t1[u].x, sr);  sr = fma(-Ti, t1[u].y, sr);
+		    si = fma(Tr, t1[u].y, si);  si = fma(Ti, t1[u].x, si);
+		    aw += in ? as[u] : 0.0f;
+		}
+	    }
+	    const double delta = dscale * (double)aw;
+	    const bool stable = (float)( mr - delta ) == (float)( mr + delta )
+			     && (float)( mi - delta ) == (float)( mi + delta )
+			     && (float)( sr - delta ) == (float)( sr + delta )
+			     && (float)( si - delta ) == (float)( si + delta );
+	    const bool wanted = active && j >= c0;
+	    if ( wanted && stable )
+		mags[( j - c0 ) * nb + k] = make_float2(band_mag(mr, mi, cfg.magscalar), band_mag(sr, si, cfg.magscalar));
+	    const unsigned long long again = __ballot(wanted && !stable);
+	    if ( g0 == 0u )
+		redo0 = again;
+	    else
+		redo1 = again;
+	}
+	const uint32_t tg2 = MIFSK_WCLOCK();
+	cyc_g_asm += tg2 - tg1;
+	// the windows whose float the bound does not settle: again, in index order
+	for ( uint32_t h = 0; h < 2u; h++ ) {
+	    const unsigned long long m = h ? redo1 : redo0;
+	    if ( !m )
+		continue;
+	    bump(21);
+	    wave_lds_sync();				// (the partials are not needed any more: their
+	    uint32_t *list = partRel;			//  space holds the list of windows)
+	    const uint32_t nredo = (uint32_t)__popcll(m);
+	    if ( ( m >> lane ) & 1ull )
+		list[__popcll(m & ( ( 1ull << lane ) - 1ull ))] = 64u * h + lane;
+	    wave_lds_sync();
+	    const uint32_t w = list[lane < nredo ? lane : 0u];
+	    const uint32_t j = udiv_magic(w, nb, cfg.nbits_magic), k = w - j * nb;
+	    const uint32_t a = base + zz.at(j) + cfg.bit_offset[k & 63u];
+	    double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
+	    corr_global_tiled(tw, x, a, nredo, B, lane, slab, acc);
+	    if ( lane < nredo )
+		mags[( j - c0 ) * nb + k] = make_float2(band_mag(acc[0], acc[1], cfg.magscalar),
+							   band_mag(acc[2], acc[3], cfg.magscalar));
+	    wave_lds_sync();
+	}
+	cyc_g_redo += MIFSK_WCLOCK() - tg2;
+    }
+
     // `reuse0`: candidate 0 of this scan is the candidate 0 of the scan just made at
     // the same cursor with the same expect string (the fine rescan after a
     // carrier-held coarse scan, minimodem.c:1373 after :1265: same try_first, same
@@ -596,7 +850,18 @@ struct Wave {
 		    bump(MIFSK_CNT_STAGES);
 	    }
 	    const uint32_t ts1 = MIFSK_WCLOCK();
-	    scan_correlate(base, zz, c0, Q, use_slab);
+	    bool shared = false;
+	    if constexpr ( NQ == kTiled ) {
+		// long windows, the whole (rest of the) scan in this chunk, far enough from the
+		// end of the stream that whole tile steps may be loaded behind every window
+		shared = g.tiled && !ring && zz.id < 4u && cfg.seg[zz.id & 3u].valid && c0 + Q == zz.J
+		      && base + cfg.seg[zz.id & 3u].span_hi + cfg.bit_nsamples + 192u <= N
+		      && base + cfg.seg[zz.id & 3u].span_hi + cfg.bit_nsamples + 192u >= base;
+		if ( shared )
+		    seg_correlate(base, zz, c0);
+	    }
+	    if ( !shared )
+		scan_correlate(base, zz, c0, Q, use_slab);
 	    wave_lds_sync();
 	    const uint32_t ts2 = MIFSK_WCLOCK();
 	    FrameOut f;
@@ -718,6 +983,11 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
     o.eps = io.d_episodes ? io.d_episodes + (size_t)s * io.episodes_cap : nullptr;
 
     Wave<SV, NQ> ctx(cfg, g, tw, x, N, mags, slab, ring, safe_limit, cnt, io.d_counters != nullptr);
+
+    if constexpr ( NQ == kTiled ) {
+	if ( g.tiled && cfg.seg[1].valid && cfg.seg[3].valid )
+	    ctx.plan_cache_fill();
+    }
 
     // reference loop state (minimodem.c:1079-1088,1132-1133), uniform in the wave
     bool carrier = false;
@@ -1234,8 +1504,9 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 	    c[MIFSK_CNT_CYC_WAIT] = ctx.cyc_block;
 	    c[MIFSK_CNT_CYC_CONFIDENCE] = ctx.cyc_conf;
 	    c[MIFSK_CNT_CYC_BULK] = cyc_bulk;
-	    c[13] = ctx.cyc_stage;
-	    c[14] = ctx.cyc_corr;
+	    c[13] = NQ == kTiled ? ctx.cyc_g_pass : ctx.cyc_stage;
+	    c[14] = NQ == kTiled ? ctx.cyc_g_asm : ctx.cyc_corr;
+	    c[15] = ctx.cyc_g_redo;
 	    c[16] = cyc_general;
 	    c[17] = ctx.cyc_s_stage;
 	    c[18] = ctx.cyc_s_corr;
@@ -1351,6 +1622,12 @@ bool plan_for( const DevCfg &cfg, const WaveHostArgs &ha, int sv, size_t budget,
 	    if ( g.lat_mode == LAT_LINEAR )
 		g.lat_mode = LAT_DIRECT;	// (that instantiation has no staged rounds)
 	    sf = TILE_FLOATS;
+	    bool any = false;
+	    for ( int i = 0; i < 4; i++ )
+		any = any || cfg.seg[i].valid;
+	    if ( any )			// shared segments: partial sums [SEG_MAX] x (4 doubles, |x| sum, start)
+		sf += (size_t)SEG_MAX * ( 4u * sizeof(double) + 2u * sizeof(float) ) / sizeof(float)
+		    + 2u * ( 2u * SEG_MAX + SEG_MAX / 4u );	// ... and the carrier-held scans' plan words
 	}
 	const size_t total = kCntBytes + (size_t)g.mags_cap * sizeof(float2) + sf * 4u + 16u;
 	if ( total <= budget ) {
@@ -1424,9 +1701,11 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
 	// nothing keeps the SCAN slab in LDS (RTTY: 1056-sample windows, a 40 kB
 	// span; 0.5 baud: 96000-sample windows): the windows come from global
 	// memory through a 17 kB tile, two waves per SIMD
-	const uint32_t wpc = want < 8u ? want : 8u;
-	const size_t budget = ( kLdsPerCu / wpc ) & ~(size_t)255;
-	ok = plan_for(cfg, ha, 10, budget, plan, true) && plan.g.tiled;
+	// (with the shared segments' partial sums behind the tile, seven waves per CU)
+	for ( uint32_t wpc = want < 8u ? want : 8u; wpc >= 4u && !ok; wpc-- ) {
+	    const size_t budget = ( kLdsPerCu / wpc ) & ~(size_t)255;
+	    ok = plan_for(cfg, ha, 10, budget, plan, true) && plan.g.tiled;
+	}
     }
     if ( !ok ) {
 	// ... or straight into registers, a window per lane
