@@ -72,19 +72,52 @@ static void plan_segments( SegPlan &sp, const mifsk_rx_config &c, unsigned first
     }
     if ( segs.empty() || segs.size() > (size_t)SEG_MAX )
 	return;
-    const unsigned npass = (unsigned)( ( segs.size() + 63 ) / 64 );
-    const size_t cap = 64u * npass;
-    while ( segs.size() < cap ) {			// balance: halve the longest piece
-	size_t m = 0;
-	for ( size_t i = 1; i < segs.size(); i++ )
-	    if ( segs[i].len > segs[m].len ) m = i;
-	if ( segs[m].len < 96 )
-	    break;
-	const unsigned h = ( segs[m].len / 2 + 3 ) & ~3u;
-	const Seg tail{segs[m].rel + h, segs[m].len - h};
-	segs[m].len = h;
-	segs.insert(segs.begin() + (long)m + 1, tail);
+    // Balance.  Every piece may be cut further, into k equal parts; with a target length T
+    // piece i gets k_i = ceil(len_i / T) parts.  The parts go to (at most two) passes of 64
+    // lanes, longest first, and a pass costs as many groups of 16 samples as its longest
+    // part has: take the T that makes the passes cheapest.
+    {
+	const std::vector<Seg> pieces = segs;
+	unsigned best_cost = 0xFFFFFFFFu, best_T = 0;
+	std::vector<unsigned> cand;
+	for ( const Seg &s : pieces )
+	    for ( unsigned k = 1; k <= 16u && s.len / k >= 16u; k++ )
+		cand.push_back(( s.len + k - 1 ) / k);
+	std::sort(cand.begin(), cand.end());
+	cand.erase(std::unique(cand.begin(), cand.end()), cand.end());
+	for ( unsigned T : cand ) {
+	    std::vector<unsigned> lens;
+	    for ( const Seg &s : pieces ) {
+		const unsigned k = ( s.len + T - 1 ) / T;
+		for ( unsigned q = 0; q < k; q++ )
+		    lens.push_back(s.len / k + ( q < s.len % k ? 1u : 0u ));
+	    }
+	    if ( lens.size() > (size_t)SEG_MAX )
+		continue;
+	    std::sort(lens.begin(), lens.end(), [](unsigned a, unsigned b) { return a > b; });
+	    // (per pass: its groups of 16 samples, plus what a pass costs whatever its length)
+	    unsigned cost = ( lens[0] + 15 ) / 16 + 1;
+	    if ( lens.size() > 64 )
+		cost += ( lens[64] + 15 ) / 16 + 1;
+	    if ( cost < best_cost ) {
+		best_cost = cost;
+		best_T = T;
+	    }
+	}
+	if ( !best_T )
+	    return;
+	segs.clear();
+	for ( const Seg &s : pieces ) {
+	    const unsigned k = ( s.len + best_T - 1 ) / best_T;
+	    unsigned at = s.rel;
+	    for ( unsigned q = 0; q < k; q++ ) {
+		const unsigned l = s.len / k + ( q < s.len % k ? 1u : 0u );
+		segs.push_back(Seg{at, l});
+		at += l;
+	    }
+	}
     }
+    const unsigned npass = (unsigned)( ( segs.size() + 63 ) / 64 );
     // passes: longest pieces first, position order inside a pass
     std::vector<unsigned> order(segs.size());
     for ( size_t i = 0; i < order.size(); i++ ) order[i] = (unsigned)i;
@@ -181,6 +214,9 @@ void fill_devcfg( DevCfg &d, const mifsk_rx_config &c )
     d.rx_one = c.rx_one ? 1u : 0u;
     d.sync_byte = c.sync_byte;
     d.b_mark = c.b_mark;
+    d.b_space = c.b_space;
+    d.fftsize = (uint32_t)c.fftsize;
+
     // One pad word per bit row of a SCAN slab where that spreads the lanes of a
     // search over more LDS banks: the first 64 windows of the carrier-held fine
     // search (lane = candidate * n_bits + bit, ds_read_b32, 32 lanes per LDS
@@ -341,8 +377,11 @@ extern "C" void mifsk_ctx_destroy( mifsk_ctx *ctx )
 	return;
     for ( TwEntry &e : ctx->tables )
 	(void)hipFree(e.d_tw);
-    for ( CfgEntry &e : ctx->configs )
+    for ( CfgEntry &e : ctx->configs ) {
 	(void)hipFree(e.dev);
+	for ( double *r : e.d_rot )
+	    if ( r ) (void)hipFree(r);
+    }
     if ( ctx->host )
 	mifsk::host_work_destroy(ctx->host);
     delete ctx;
@@ -380,8 +419,11 @@ static void cache_gc( mifsk_ctx *ctx )
     std::unique_lock<std::shared_mutex> x(ctx->gate);
     std::lock_guard<std::mutex> g(ctx->lock);
     (void)hipDeviceSynchronize();
-    for ( CfgEntry &e : ctx->configs )
+    for ( CfgEntry &e : ctx->configs ) {
 	(void)hipFree(e.dev);
+	for ( double *r : e.d_rot )
+	    if ( r ) (void)hipFree(r);
+    }
     ctx->configs.clear();
     for ( TwEntry &e : ctx->tables )
 	(void)hipFree(e.d_tw);
@@ -415,19 +457,49 @@ static int get_twiddles( mifsk_ctx *ctx, const TwKey &key, const double **d_out 
     return 0;
 }
 
-static int get_devcfg( mifsk_ctx *ctx, const DevCfg &d, const DevCfg **d_out )
+static int get_devcfg( mifsk_ctx *ctx, const DevCfg &d, const DevCfg **d_out, CfgEntry *entry_out = nullptr )
 {
     std::lock_guard<std::mutex> g(ctx->lock);
     for ( const CfgEntry &e : ctx->configs )
 	if ( std::memcmp(&e.host, &d, sizeof(DevCfg)) == 0 ) {
 	    *d_out = e.dev;
+	    if ( entry_out ) *entry_out = e;		// (a copy: the vector may grow under another caller)
 	    return 0;
 	}
     DevCfg *dev = nullptr;
     HIP_OK(hipMalloc(&dev, sizeof(DevCfg)));
     HIP_OK(hipMemcpy(dev, &d, sizeof(DevCfg), hipMemcpyHostToDevice));
-    ctx->configs.push_back(CfgEntry{d, dev});
+    CfgEntry ce;
+    ce.host = d;
+    ce.dev = dev;
+    // shared segments: every window's rotation factors, [segment of the window][window]
+    for ( int k = 0; k < 4; k++ ) {
+	ce.d_rot[k] = nullptr;
+	ce.rot_stride[k] = 0;
+	const mifsk::SegPlan &sp = d.seg[k];
+	if ( !sp.valid )
+	    continue;
+	unsigned cmax = 0;
+	for ( unsigned w = 0; w < sp.nwin; w++ )
+	    cmax = sp.win_count[w] > cmax ? sp.win_count[w] : cmax;
+	const unsigned stride = ( sp.nwin + 63u ) & ~63u;
+	std::vector<double> h((size_t)cmax * stride * 4, 0.0);
+	for ( unsigned w = 0; w < sp.nwin; w++ )
+	    for ( unsigned i = 0; i < sp.win_count[w]; i++ ) {
+		const unsigned off = sp.seg_rel[sp.win_first[w] + i] - ( sp.p_win[w] >> 16 );
+		double *t = &h[( (size_t)i * stride + w ) * 4];
+		twiddle(d.b_mark, off, d.fftsize, t);
+		twiddle(d.b_space, off, d.fftsize, t + 2);
+	    }
+	if ( hipMalloc(&ce.d_rot[k], h.size() * sizeof(double)) != hipSuccess
+		|| hipMemcpy(ce.d_rot[k], h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess )
+	    return -ENOMEM;
+	ce.rot_stride[k] = stride;
+	ctx->table_bytes += h.size() * sizeof(double);
+    }
+    ctx->configs.push_back(ce);
     *d_out = dev;
+    if ( entry_out ) *entry_out = ce;
     return 0;
 }
 
@@ -524,7 +596,7 @@ static bool use_workgroup_engine( const mifsk_rx_config *cfg, const DevCfg &d, u
 static int demod_batch_wave( mifsk_ctx *ctx, const mifsk_rx_config *cfg, const DevCfg &d,
 	const DevCfg *d_cfg, const double *d_tw, const mifsk_demod_io *io, void *stream,
 	mifsk::LaunchInfo *plan_only = nullptr, mifsk_stream_state *d_state = nullptr,
-	const uint64_t *d_origin = nullptr, bool final = true )
+	const uint64_t *d_origin = nullptr, bool final = true, const CfgEntry *tables = nullptr )
 {
     hipStream_t st = (hipStream_t)stream;
     const size_t ns = (size_t)io->nstreams;
@@ -538,6 +610,12 @@ static int demod_batch_wave( mifsk_ctx *ctx, const mifsk_rx_config *cfg, const D
     ha.d_state = d_state;
     ha.d_origin = d_origin;
     ha.final = final;
+    // (--auto-carrier retunes per stream: its rotation factors come from the stream's own table)
+    if ( tables && !( cfg->auto_carrier_threshold > 0.0f ) )
+	for ( int k = 0; k < 4; k++ ) {
+	    ha.d_rot[k] = tables->d_rot[k];
+	    ha.rot_stride[k] = tables->rot_stride[k];
+	}
     if ( plan_only ) {
 	ha.ring_exact = ( io->flags & MIFSK_IO_RING_EXACT ) != 0;
 	ha.autodetect = cfg->auto_carrier_threshold > 0.0f;
@@ -616,14 +694,15 @@ extern "C" int mifsk_demod_batch( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
     DevCfg d;
     mifsk::fill_devcfg(d, *cfg);
     const DevCfg *d_cfg = nullptr;
-    rc = get_devcfg(ctx, d, &d_cfg);
+    CfgEntry tables;
+    rc = get_devcfg(ctx, d, &d_cfg, &tables);
     if ( rc )
 	return rc;
     if ( io->nstreams == 0 )
 	return 0;
     const bool workgroup = use_workgroup_engine(cfg, d, io->flags);
     if ( !workgroup )
-	return demod_batch_wave(ctx, cfg, d, d_cfg, d_tw, io, stream);
+	return demod_batch_wave(ctx, cfg, d, d_cfg, d_tw, io, stream, nullptr, nullptr, nullptr, true, &tables);
     return mifsk::launch_demod_batch(d, d_cfg, d_tw, *io, stream);
 }
 
@@ -667,10 +746,11 @@ extern "C" int mifsk_demod_slab( mifsk_ctx *ctx, const mifsk_rx_config *cfg, con
     DevCfg d;
     mifsk::fill_devcfg(d, *cfg);
     const DevCfg *d_cfg = nullptr;
-    rc = get_devcfg(ctx, d, &d_cfg);
+    CfgEntry tables;
+    rc = get_devcfg(ctx, d, &d_cfg, &tables);
     if ( rc )
 	return rc;
-    return demod_batch_wave(ctx, cfg, d, d_cfg, d_tw, io, stream, nullptr, d_state, d_origin, final != 0);
+    return demod_batch_wave(ctx, cfg, d, d_cfg, d_tw, io, stream, nullptr, d_state, d_origin, final != 0, &tables);
 }
 
 // what mifsk_demod_batch would launch for this configuration and batch size

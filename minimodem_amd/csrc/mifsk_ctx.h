@@ -37,6 +37,9 @@ struct TwEntry {
 struct CfgEntry {
     DevCfg	host;
     DevCfg	*dev;
+    // shared segments: rotation tables of the four scans (mifsk_device.h WaveAuto::d_rot)
+    double	*d_rot[4];
+    uint32_t	rot_stride[4];
 };
 
 struct mifsk_ctx {

@@ -77,6 +77,7 @@ struct DevCfg {
     // F (n_bits - 1) + 1 distinct windows
     uint32_t	lat_grid;
     uint32_t	b_mark;			// the plan's mark band (episodes report it)
+    uint32_t	b_space, fftsize;	// (with b_mark: what the shared segments' rotation tables are made for)
     // closed form of the four zig-zag scans of the receive loop (fsk.c:477-484; ZigZag in
     // mifsk_devlib.h): up / down candidate counts of [0] coarse without carrier, [1] coarse with
     // carrier, [2] fine without, [3] fine with (minimodem.c:1236-1263,1366)
@@ -157,6 +158,12 @@ struct WaveAuto {
     mifsk_stream_state	*d_state;
     const uint64_t	*d_origin;	// stream index of each row's first sample (NULL: 0)
     uint32_t		final;		// the rows end where the streams end
+    // shared segments: the rotation factor of segment i of window w of scan `kind`, laid out
+    // [i][w] so that the lanes of the assembly (lane = window) read consecutive entries:
+    // d_rot[kind][(i * rot_stride[kind] + w) * 4 .. + 3] = table entry of the segment's offset
+    // inside the window (NULL: gathered from the stream's own table -- --auto-carrier)
+    const double	*d_rot[4];
+    uint32_t		rot_stride[4];
 };
 
 // what the host glue hands the launcher besides cfg / io
@@ -177,6 +184,8 @@ struct WaveHostArgs {
     mifsk_stream_state *d_state;
     const uint64_t *d_origin;
     bool	final;
+    const double *d_rot[4];
+    uint32_t	rot_stride[4];
 };
 
 int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_tw,

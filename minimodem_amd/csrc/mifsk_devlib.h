@@ -829,37 +829,47 @@ __device__ __forceinline__ void corr_global_stream( const double *__restrict__ t
 // lockstep means one load instruction touches 64 different cache lines, which the
 // CU's address path serves at ~1.2 cycles per line (78-90 cycles per
 // global_load_dwordx4, tools/ubench/ta_rate.hip) and which uses 16 of the 128
-// bytes each line fill brings in.  Here the wave fetches TILE_K = 64 samples of
-// every window per step with loads in which 16 adjacent lanes read 256
-// contiguous bytes of ONE window (4 windows per load, 16 cycles each), parks them
-// in an LDS tile -- row w = the 64 samples of window w, rows TILE_ROW floats apart
-// -- and every lane reads its own row back with aligned ds_read_b128 (row stride
-// 68 words: conflict-free in every 16-lane group).  One tile per wave, no
-// barrier: a wave's LDS operations execute in order.  tools/ubench/longwin.hip:
-// 33.7 -> 17.5 ms for the RTTY batch.
-constexpr uint32_t TILE_K = 64u;
+// bytes each line fill brings in.  Here the wave fetches TILE_K samples of every
+// window per step with loads in which TILE_K / 4 adjacent lanes read the
+// contiguous bytes of ONE window, parks them in an LDS tile -- row w = the TILE_K
+// samples of window w, rows TILE_ROW floats apart -- and every lane reads its own
+// row back with aligned ds_read_b128 (row stride 4 words off a multiple of 32:
+// conflict-free in every 8-lane group).  One tile per wave, no barrier: a wave's LDS
+// operations execute in order.  tools/ubench/longwin.hip: 33.7 -> 17.5 ms for the RTTY
+// batch with 64 samples per step.
+// [r3] 32 samples per step (one 128-byte line per window and load): the receive loop of
+// these modes is a serial chain per stream whose time does not depend on how many other
+// streams share the CU (measured: 6 / 5 / 4 / 3 waves per CU -> 14.4 / 17.7 / 17.7 / 28.5 ms
+// for 4096 RTTY streams), so what counts is how many waves fit: a 9 kB tile, with the
+// shared segments' partial sums aliased onto it, lets twelve waves share a CU's LDS
+// where the 17 kB tile allowed six.
+constexpr uint32_t TILE_K = 32u;
 constexpr uint32_t TILE_ROW = TILE_K + 4u;
 constexpr uint32_t TILE_FLOATS = 64u * TILE_ROW;
+constexpr uint32_t TILE_LPW = TILE_K / 4u;		// lanes that fetch one window's step (16 bytes each)
+constexpr uint32_t TILE_WPL = 64u / TILE_LPW;		// windows per load instruction
+constexpr int TILE_GPS = (int)( TILE_K / 16u );		// groups of 16 samples per step
+constexpr uint32_t kTileMinBit = 256u;			// bit lengths from here on may go through the tile
 
-// NLD loads per step: windows 0 .. 4 NLD - 1.  Straight-line steps: every load and
-// store of a step is unconditional (a conditional load leaves the compiler with
+// NLD loads per step: windows 0 .. TILE_WPL NLD - 1.  Straight-line steps: every load
+// and store of a step is unconditional (a conditional load leaves the compiler with
 // an outstanding counter at the join and it waits for everything there).
 template <int NLD>
 __device__ __forceinline__ void corr_global_tiled_n( const double *__restrict__ tw, const float *__restrict__ x,
 	uint32_t a, uint32_t B, uint32_t lane, float *tile, double (&acc)[4] )
 {
-    const uint32_t sub = lane & 15u, grp = lane >> 4;
-    // load i of a step: lanes 16j .. 16j+15 read samples of window 4i + j
+    const uint32_t sub = lane % TILE_LPW, grp = lane / TILE_LPW;
+    // load i of a step: lanes TILE_LPW j .. TILE_LPW j + TILE_LPW - 1 read samples of window TILE_WPL i + j
     uint32_t off[NLD];
 #pragma unroll
     for ( int i = 0; i < NLD; i++ )
-	off[i] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)( ( 4u * (uint32_t)i + grp ) << 2 ), (int)a) + 4u * sub;
-    float *wr = tile + grp * TILE_ROW + 4u * sub;	// + 4 i rows
+	off[i] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)( ( TILE_WPL * (uint32_t)i + grp ) << 2 ), (int)a) + 4u * sub;
+    float *wr = tile + grp * TILE_ROW + 4u * sub;	// + TILE_WPL i rows
     const float *rd = tile + lane * TILE_ROW;
     const uint32_t ngf = B >> 4;			// whole groups of 16 samples
     const uint32_t tail = B & 15u;			// samples of the last, short group
-    const uint32_t nfull = ngf >> 2;			// steps of four whole groups
-    const uint32_t rest = ngf & 3u;			// whole groups of the last, short step
+    const uint32_t nfull = ngf / (uint32_t)TILE_GPS;	// steps of whole groups
+    const uint32_t rest = ngf % (uint32_t)TILE_GPS;	// whole groups of the last, short step
     const uint32_t last_step = ( rest | tail ) ? nfull : nfull - 1u;
     float4 L[NLD];
 #define MIFSK_TILE_FETCH(S)								\
@@ -871,45 +881,25 @@ __device__ __forceinline__ void corr_global_tiled_n( const double *__restrict__ 
 #define MIFSK_TILE_WRITE()								\
     _Pragma("unroll")									\
     for ( int i = 0; i < NLD; i++ )							\
-	*reinterpret_cast<float4 *>(wr + 4u * (uint32_t)i * TILE_ROW) = L[i];
-#define MIFSK_TILE_READ(XS, H)								\
-    _Pragma("unroll")									\
-    for ( int j = 0; j < 4; j++ )							\
-	XS[j] = *reinterpret_cast<const float4 *>(rd + 16 * (H) + 4 * j);
+	*reinterpret_cast<float4 *>(wr + TILE_WPL * (uint32_t)i * TILE_ROW) = L[i];
     MIFSK_TILE_FETCH(0u)
     TwGroup G = tw_group_load(tw, 0, lane);
     for ( uint32_t s = 0; s < nfull; s++ ) {
 	MIFSK_TILE_WRITE()
 	const uint32_t sn = s < last_step ? s + 1u : last_step;		// (the last step is fetched twice)
 	MIFSK_TILE_FETCH(sn)
-	float4 xa[4], xb[4];
-	MIFSK_TILE_READ(xa, 0)
+	float4 xs[TILE_GPS][4];
+#pragma unroll
+	for ( int h = 0; h < TILE_GPS; h++ )
+#pragma unroll
+	    for ( int j = 0; j < 4; j++ )
+		xs[h][j] = *reinterpret_cast<const float4 *>(rd + 16 * h + 4 * j);
 	// (the table is padded by a group: loading group g + 1 is always legal)
-	{
-	    const TwGroup Gn = tw_group_load(tw, 4u * s + 1u, lane);
-	    MIFSK_TILE_READ(xb, 1)
+#pragma unroll
+	for ( int h = 0; h < TILE_GPS; h++ ) {
+	    const TwGroup Gn = tw_group_load(tw, (uint32_t)TILE_GPS * s + (uint32_t)h + 1u, lane);
 	    dpp_settle();
-	    group_bcast(acc, G, xa[0], xa[1], xa[2], xa[3]);
-	    G = Gn;
-	}
-	{
-	    const TwGroup Gn = tw_group_load(tw, 4u * s + 2u, lane);
-	    MIFSK_TILE_READ(xa, 2)
-	    dpp_settle();
-	    group_bcast(acc, G, xb[0], xb[1], xb[2], xb[3]);
-	    G = Gn;
-	}
-	{
-	    const TwGroup Gn = tw_group_load(tw, 4u * s + 3u, lane);
-	    MIFSK_TILE_READ(xb, 3)
-	    dpp_settle();
-	    group_bcast(acc, G, xa[0], xa[1], xa[2], xa[3]);
-	    G = Gn;
-	}
-	{
-	    const TwGroup Gn = tw_group_load(tw, 4u * s + 4u, lane);
-	    dpp_settle();
-	    group_bcast(acc, G, xb[0], xb[1], xb[2], xb[3]);
+	    group_bcast(acc, G, xs[h][0], xs[h][1], xs[h][2], xs[h][3]);
 	    G = Gn;
 	}
     }
@@ -918,7 +908,7 @@ __device__ __forceinline__ void corr_global_tiled_n( const double *__restrict__ 
 	MIFSK_TILE_WRITE()
 	float4 xs[4];
 	for ( uint32_t h = 0; h < rest; h++ ) {
-	    const TwGroup Gn = tw_group_load(tw, 4u * nfull + h + 1u, lane);
+	    const TwGroup Gn = tw_group_load(tw, (uint32_t)TILE_GPS * nfull + h + 1u, lane);
 	    const float *r = rd + 16u * h;
 #pragma unroll
 	    for ( int j = 0; j < 4; j++ )
@@ -938,17 +928,18 @@ __device__ __forceinline__ void corr_global_tiled_n( const double *__restrict__ 
     }
 #undef MIFSK_TILE_FETCH
 #undef MIFSK_TILE_WRITE
-#undef MIFSK_TILE_READ
 }
 
 // ---------------------------------------------------------------------------
 // Shared segments (SegPlan, mifsk_device.h; Wave::seg_correlate): through the same tile
 // every lane sums a SEGMENT of its own length `len` (at most the pass's lock-step length)
 // -- samples at or beyond a lane's length enter as 0.0, which leaves its sums untouched
-// -- and keeps the sum of |x| over its segment for the error bound.  One group of 16
+// -- and keeps the sum of x^2 over its segment for the error bound.  One group of 16
 // samples; groups that lie below the pass's shortest segment need no mask (`whole`).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void seg_group( double (&acc)[4], float &asum, const TwGroup &G,
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void seg_group( double (&acc)[4], float2v &esum, const TwGroup &G,
 	float4 s0, float4 s1, float4 s2, float4 s3, uint32_t n0, uint32_t len, bool whole )
 {
     if ( !whole ) {
@@ -961,23 +952,29 @@ __device__ __forceinline__ void seg_group( double (&acc)[4], float &asum, const 
     }
     dpp_settle();
     group_bcast(acc, G, s0, s1, s2, s3);
-    asum += ( ( ( fabsf(s0.x) + fabsf(s0.y) ) + ( fabsf(s0.z) + fabsf(s0.w) ) )
-	    + ( ( fabsf(s1.x) + fabsf(s1.y) ) + ( fabsf(s1.z) + fabsf(s1.w) ) ) )
-	  + ( ( ( fabsf(s2.x) + fabsf(s2.y) ) + ( fabsf(s2.z) + fabsf(s2.w) ) )
-	    + ( ( fabsf(s3.x) + fabsf(s3.y) ) + ( fabsf(s3.z) + fabsf(s3.w) ) ) );
+    // sum of squares, two samples per instruction (v_pk_fma_f32): the error bound takes
+    // sum |x| <= sqrt(n * sum x^2) from it
+    esum = __builtin_elementwise_fma(float2v{s0.x, s0.y}, float2v{s0.x, s0.y}, esum);
+    esum = __builtin_elementwise_fma(float2v{s0.z, s0.w}, float2v{s0.z, s0.w}, esum);
+    esum = __builtin_elementwise_fma(float2v{s1.x, s1.y}, float2v{s1.x, s1.y}, esum);
+    esum = __builtin_elementwise_fma(float2v{s1.z, s1.w}, float2v{s1.z, s1.w}, esum);
+    esum = __builtin_elementwise_fma(float2v{s2.x, s2.y}, float2v{s2.x, s2.y}, esum);
+    esum = __builtin_elementwise_fma(float2v{s2.z, s2.w}, float2v{s2.z, s2.w}, esum);
+    esum = __builtin_elementwise_fma(float2v{s3.x, s3.y}, float2v{s3.x, s3.y}, esum);
+    esum = __builtin_elementwise_fma(float2v{s3.z, s3.w}, float2v{s3.z, s3.w}, esum);
 }
 
 //   a     absolute start of this lane's window (idle lanes: any valid window)
 //   nwin  lanes 0 .. nwin-1 hold windows (uniform)
-// The caller guarantees a + 64 * ceil(B / 64) <= N for every lane (whole steps
+// The caller guarantees a + TILE_K * ceil(B / TILE_K) <= N for every lane (whole steps
 // are loaded; what lies beyond B is not accumulated).
 __device__ __forceinline__ void corr_global_tiled( const double *__restrict__ tw, const float *__restrict__ x,
 	uint32_t a, uint32_t nwin, uint32_t B, uint32_t lane, float *tile, double (&acc)[4] )
 {
     if ( nwin > 32u )
-	corr_global_tiled_n<16>(tw, x, a, B, lane, tile, acc);
+	corr_global_tiled_n<(int)( 64u / TILE_WPL )>(tw, x, a, B, lane, tile, acc);
     else
-	corr_global_tiled_n<8>(tw, x, a, B, lane, tile, acc);
+	corr_global_tiled_n<(int)( 32u / TILE_WPL )>(tw, x, a, B, lane, tile, acc);
 }
 
 // Window in a slab WITHOUT pad words (cfg.skew == 0), at any alignment: the

@@ -209,6 +209,7 @@ struct Wave {
     uint32_t		cyc_g_pass = 0, cyc_g_asm = 0, cyc_g_redo = 0;	// shared-segment SCAN: passes, assembly, index-order repeats
 
 
+
     __device__ __forceinline__ Wave( const DevCfg &c, const WaveGeom &gg, const double *t,
 	    const float *xs, uint32_t n, float2 *m, float *s, float *r,uint32_t safe, uint32_t *counters, bool counting )
 	: cfg(c), g(gg), tw(t), x(xs), N(n), mags(m), slab(s), ring(r), lane(threadIdx.x),
@@ -537,12 +538,12 @@ struct Wave {
     // windows where it is not are summed again in index order (corr_global_tiled).
     // Fills mags[(j - c0) * n_bits + k] for candidates j = c0 .. J-1 of `zz`.
     // ------------------------------------------------------------------
-    // The packed plan words of the two carrier-held scans (kinds 1 and 3) are copied into LDS
-    // once per stream; the acquisition scans read theirs from the plan in device memory.
+    // LDS of the tiled instantiation: [tile | plan words of the two carrier-held scans | list].
+    // The partial sums live ON the tile between the passes and the assembly.
     static constexpr uint32_t kPlanWords = 2u * SEG_MAX + SEG_MAX / 4u;	// p_slot, p_win, p_slot_seg per kind
     __device__ __forceinline__ uint32_t *plan_cache() const
     {
-	return reinterpret_cast<uint32_t *>(slab + TILE_FLOATS) + SEG_MAX * ( 4u * 2u + 2u );	// behind the partials
+	return reinterpret_cast<uint32_t *>(slab + TILE_FLOATS);
     }
     __device__ __forceinline__ void plan_cache_fill()
     {
@@ -563,11 +564,20 @@ struct Wave {
     __device__ __forceinline__ void seg_correlate( uint32_t base, const ZigZag &zz, uint32_t c0 )
     {
 	const uint32_t kind = zz.id & 3u;
+	// (read where it is used, from the kernarg segment: KernArgs in mifsk_devlib.h)
+	const KernArgs<WaveArgs>::ptr ka = KernArgs<WaveArgs>::here();
+	const double *rot = ka->au.d_rot[kind];		// (uniform) NULL: gather from the stream's table
+	const uint32_t rstride = ka->au.rot_stride[kind];
 	const SegPlan &sp = cfg.seg[kind];
 	const uint32_t nb = cfg.n_bits, B = cfg.bit_nsamples;
-	double *partD = reinterpret_cast<double *>(slab + TILE_FLOATS);		// [SEG_MAX][4]
-	float *partA = reinterpret_cast<float *>(partD + 4 * SEG_MAX);		// [SEG_MAX]
-	uint32_t *partRel = reinterpret_cast<uint32_t *>(partA + SEG_MAX);	// [SEG_MAX]
+	// (one entry more than there can be segments: an all-zero partial sum, what the lanes
+	// of the assembly read once their own window's segments are used up)
+	constexpr uint32_t kParts = SEG_MAX + 1u;
+	static_assert(kParts * ( 4 * sizeof(double) + 2 * sizeof(float) ) <= TILE_FLOATS * sizeof(float),
+		      "the partial sums are kept on the tile");
+	double *partD = reinterpret_cast<double *>(slab);			// [kParts][4]
+	float *partA = reinterpret_cast<float *>(partD + 4 * kParts);		// [kParts]
+	uint32_t *partRel = reinterpret_cast<uint32_t *>(partA + kParts);	// [kParts]
 	const bool cached = ( kind & 1u ) != 0u && cfg.seg[1].valid && cfg.seg[3].valid;
 	const uint32_t *pc = plan_cache() + ( kind >> 1 ) * kPlanWords;
 	const uint32_t tg0 = MIFSK_WCLOCK();
@@ -591,21 +601,27 @@ struct Wave {
 	sw1 = have1 ? sw1 : ( np > 1u ? (uint32_t)__builtin_amdgcn_readfirstlane((int)sw1) : sw0 );
 	const uint32_t rel0 = sw0 & 0xFFFFFu, len0 = sw0 >> 20, rel1 = sw1 & 0xFFFFFu, len1 = sw1 >> 20;
 	const uint32_t ng0 = ( sp.pass_len[0] + 15u ) >> 4, ng1 = np > 1u ? ( sp.pass_len[1] + 15u ) >> 4 : 0u;
-	const uint32_t ns0 = ( ng0 + 3u ) >> 2, ns1 = ( ng1 + 3u ) >> 2;
+	const uint32_t ns0 = ( ng0 + (uint32_t)TILE_GPS - 1u ) / (uint32_t)TILE_GPS;
+	const uint32_t ns1 = ( ng1 + (uint32_t)TILE_GPS - 1u ) / (uint32_t)TILE_GPS;
 	const uint32_t min0 = sp.pass_min[0], min1 = sp.pass_min[1];
+	// the first pass's sums wait in registers while the second one uses the tile
+	double hold[4] = { 0.0, 0.0, 0.0, 0.0 };
+	float hold_a = 0.0f;
+	double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
+	float2v esum = { 0.0f, 0.0f };			// sum of x^2 over the segment (two running halves)
 	{
 	    // Both passes in ONE run of tile steps: while the last step of the first pass is
 	    // summed, the first step of the second is already on its way (corr_global_tiled's
-	    // scheme -- 16 lanes fetch 64 contiguous samples of one segment, every lane reads
-	    // its own row back -- with a per-lane length, see seg_group)
-	    constexpr int NLD = 16;
-	    const uint32_t sub = lane & 15u, grp = lane >> 4;
+	    // scheme -- TILE_LPW lanes fetch the TILE_K contiguous samples of one segment, every
+	    // lane reads its own row back -- with a per-lane length, see seg_group)
+	    constexpr int NLD = (int)( 64u / TILE_WPL );
+	    const uint32_t sub = lane % TILE_LPW, grp = lane / TILE_LPW;
 	    const uint32_t a0 = base + rel0, a1 = base + rel1;
 	    uint32_t off0[NLD], off1[NLD];
 #pragma unroll
 	    for ( int i = 0; i < NLD; i++ ) {
-		off0[i] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)( ( 4u * (uint32_t)i + grp ) << 2 ), (int)a0) + 4u * sub;
-		off1[i] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)( ( 4u * (uint32_t)i + grp ) << 2 ), (int)a1) + 4u * sub;
+		off0[i] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)( ( TILE_WPL * (uint32_t)i + grp ) << 2 ), (int)a0) + 4u * sub;
+		off1[i] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)( ( TILE_WPL * (uint32_t)i + grp ) << 2 ), (int)a1) + 4u * sub;
 	    }
 	    float *wr = slab + grp * TILE_ROW + 4u * sub;
 	    const float *rd = slab + lane * TILE_ROW;
@@ -617,67 +633,44 @@ struct Wave {
 		const float4_u v = *reinterpret_cast<const float4_u *>(x + o_ + TILE_K * (S));	\
 		L[i] = make_float4(v.x, v.y, v.z, v.w);						\
 	    }
-#define MIFSK_SEGP_READ(XS, H)									\
-	    _Pragma("unroll")									\
-	    for ( int j = 0; j < 4; j++ )							\
-		XS[j] = *reinterpret_cast<const float4 *>(rd + 16 * (H) + 4 * j);
 	    MIFSK_SEGP_FETCH(false, 0u)
 	    TwGroup G = tw_group_load(tw, 0, lane);
-	    double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
-	    float asum = 0.0f;
 	    uint32_t ps = 0, ls = 0;
 	    const uint32_t total = ns0 + ( np > 1u ? ns1 : 0u );
 	    for ( uint32_t t = 0; t < total; t++ ) {
 #pragma unroll
 		for ( int i = 0; i < NLD; i++ )
-		    *reinterpret_cast<float4 *>(wr + 4u * (uint32_t)i * TILE_ROW) = L[i];
+		    *reinterpret_cast<float4 *>(wr + TILE_WPL * (uint32_t)i * TILE_ROW) = L[i];
 		const bool last = ls + 1u == ( ps ? ns1 : ns0 );
 		const bool turn = last && ps + 1u < np;			// the next step opens the second pass
 		const bool use1 = turn || ps == 1u;
 		const uint32_t sn = turn ? 0u : ( last ? ls : ls + 1u );	// (the very last step is fetched twice)
 		MIFSK_SEGP_FETCH(use1, sn)
-		const uint32_t g0 = 4u * ls;
+		const uint32_t g0 = (uint32_t)TILE_GPS * ls;
 		const uint32_t ng = ps ? ng1 : ng0, len = ps ? len1 : len0, lmin = ps ? min1 : min0;
-		float4 xa[4], xb[4];
-		MIFSK_SEGP_READ(xa, 0)
-		{
-		    const TwGroup Gn = tw_group_load(tw, g0 + 1u, lane);
-		    MIFSK_SEGP_READ(xb, 1)
-		    seg_group(acc, asum, G, xa[0], xa[1], xa[2], xa[3], 16u * g0, len, 16u * g0 + 16u <= lmin);
-		    G = Gn;
-		}
-		{
-		    const TwGroup Gn = tw_group_load(tw, g0 + 2u, lane);
-		    MIFSK_SEGP_READ(xa, 2)
-		    if ( g0 + 1u < ng )
-			seg_group(acc, asum, G, xb[0], xb[1], xb[2], xb[3], 16u * ( g0 + 1u ), len, 16u * g0 + 32u <= lmin);
-		    G = Gn;
-		}
-		{
-		    const TwGroup Gn = tw_group_load(tw, g0 + 3u, lane);
-		    MIFSK_SEGP_READ(xb, 3)
-		    if ( g0 + 2u < ng )
-			seg_group(acc, asum, G, xa[0], xa[1], xa[2], xa[3], 16u * ( g0 + 2u ), len, 16u * g0 + 48u <= lmin);
-		    G = Gn;
-		}
-		{
-		    const TwGroup Gn = tw_group_load(tw, last ? 0u : g0 + 4u, lane);
-		    if ( g0 + 3u < ng )
-			seg_group(acc, asum, G, xb[0], xb[1], xb[2], xb[3], 16u * ( g0 + 3u ), len, 16u * g0 + 64u <= lmin);
+		float4 xs[TILE_GPS][4];
+#pragma unroll
+		for ( int h = 0; h < TILE_GPS; h++ )
+#pragma unroll
+		    for ( int j = 0; j < 4; j++ )
+			xs[h][j] = *reinterpret_cast<const float4 *>(rd + 16 * h + 4 * j);
+#pragma unroll
+		for ( int h = 0; h < TILE_GPS; h++ ) {
+		    const uint32_t gi = g0 + (uint32_t)h;
+		    // (the table has the group after the pass's last one: see plan_segments)
+		    const TwGroup Gn = tw_group_load(tw, ( last && h == TILE_GPS - 1 ) ? 0u : gi + 1u, lane);
+		    if ( gi < ng )
+			seg_group(acc, esum, G, xs[h][0], xs[h][1], xs[h][2], xs[h][3], 16u * gi, len,
+				  16u * gi + 16u <= lmin);
 		    G = Gn;
 		}
 		if ( last ) {
-		    // this pass's partial sums, by segment position
-		    const bool have = ps ? have1 : have0;
-		    const uint32_t si = ps ? si1 : si0;
-		    if ( have ) {
-			*reinterpret_cast<double2_a16 *>(partD + 4u * si) = double2_a16{acc[0], acc[1]};
-			*reinterpret_cast<double2_a16 *>(partD + 4u * si + 2u) = double2_a16{acc[2], acc[3]};
-			partA[si] = asum;
-			partRel[si] = ps ? rel1 : rel0;
+		    if ( ps == 0u && np > 1u ) {
+			hold[0] = acc[0]; hold[1] = acc[1]; hold[2] = acc[2]; hold[3] = acc[3];
+			hold_a = esum.x + esum.y;
+			acc[0] = acc[1] = acc[2] = acc[3] = 0.0;
+			esum = float2v{0.0f, 0.0f};
 		    }
-		    acc[0] = acc[1] = acc[2] = acc[3] = 0.0;
-		    asum = 0.0f;
 		    ps++;
 		    ls = 0;
 		} else {
@@ -685,14 +678,41 @@ struct Wave {
 		}
 	    }
 #undef MIFSK_SEGP_FETCH
-#undef MIFSK_SEGP_READ
+	}
+	// the tile has served: the partial sums take its place, by segment position
+	wave_lds_sync();
+	if ( lane == 0 ) {
+	    *reinterpret_cast<double2_a16 *>(partD + 4u * SEG_MAX) = double2_a16{0.0, 0.0};
+	    *reinterpret_cast<double2_a16 *>(partD + 4u * SEG_MAX + 2u) = double2_a16{0.0, 0.0};
+	    partA[SEG_MAX] = 0.0f;
+	}
+	if ( np > 1u ) {
+	    if ( have0 ) {
+		*reinterpret_cast<double2_a16 *>(partD + 4u * si0) = double2_a16{hold[0], hold[1]};
+		*reinterpret_cast<double2_a16 *>(partD + 4u * si0 + 2u) = double2_a16{hold[2], hold[3]};
+		partA[si0] = hold_a;
+		partRel[si0] = rel0;
+	    }
+	    if ( have1 ) {
+		*reinterpret_cast<double2_a16 *>(partD + 4u * si1) = double2_a16{acc[0], acc[1]};
+		*reinterpret_cast<double2_a16 *>(partD + 4u * si1 + 2u) = double2_a16{acc[2], acc[3]};
+		partA[si1] = esum.x + esum.y;
+		partRel[si1] = rel1;
+	    }
+	} else if ( have0 ) {
+	    *reinterpret_cast<double2_a16 *>(partD + 4u * si0) = double2_a16{acc[0], acc[1]};
+	    *reinterpret_cast<double2_a16 *>(partD + 4u * si0 + 2u) = double2_a16{acc[2], acc[3]};
+	    partA[si0] = esum.x + esum.y;
+	    partRel[si0] = rel0;
 	}
 	wave_lds_sync();
 	bump(20);
 	const uint32_t tg1 = MIFSK_WCLOCK();
 	cyc_g_pass += tg1 - tg0;
 	// assemble: lane = window
-	const double dscale = (double)sp.bound_c * 1.0000153 * 1.1102230246251565e-16;	// (sum |x| is a float sum)
+	// delta = bound_c * 2^-53 * sum |x|, and sum |x| <= sqrt(B * sum x^2) (the sums of squares
+	// are float sums: a little slack)
+	const double dscale = (double)sp.bound_c * 1.0001 * 1.1102230246251565e-16 * sqrt((double)B);
 	unsigned long long redo0 = 0ull, redo1 = 0ull;
 	for ( uint32_t g0 = 0; g0 < sp.nwin; g0 += 64u ) {
 	    const uint32_t w = g0 + lane;
@@ -704,36 +724,37 @@ struct Wave {
 	    const uint32_t cmax = wave_max_u32(cnt);
 	    double mr = 0.0, mi = 0.0, sr = 0.0, si = 0.0;
 	    float aw = 0.0f;
-	    constexpr int AU = 8;			// segments per turn, every load issued before the first use
+	    constexpr int AU = 4;			// segments per turn, every load issued before the first use
 	    for ( uint32_t i0 = 0; i0 < cmax; i0 += (uint32_t)AU ) {
 		double2_a16 p0[AU], p1[AU], t0[AU], t1[AU];
 		float as[AU];
 #pragma unroll
 		for ( int u = 0; u < AU; u++ ) {
 		    const uint32_t i = i0 + (uint32_t)u;
-		    const uint32_t s = first + ( i < cnt ? i : 0u );
+		    const bool in = i < cnt;
+		    const uint32_t s = in ? first + i : (uint32_t)SEG_MAX;	// (beyond its own: the zero entry)
 		    p0[u] = *reinterpret_cast<const double2_a16 *>(partD + 4u * s);
 		    p1[u] = *reinterpret_cast<const double2_a16 *>(partD + 4u * s + 2u);
 		    as[u] = partA[s];
-		    const uint32_t d = partRel[s] - a_rel;		// offset of the segment inside the window
-		    const double *t = tw + 4 * (size_t)d;
+		    const uint32_t d = in ? partRel[s] - a_rel : 0u;	// offset of the segment inside the window
+		    // its rotation factor: from the scan's own table, laid out for this loop (lanes
+		    // read side by side), or entry d of the stream's table
+		    const double *t = rot ? rot + 4 * ( (size_t)i * rstride + ww ) : tw + 4 * (size_t)d;
 		    t0[u] = *reinterpret_cast<const double2_a16 *>(t);
 		    t1[u] = *reinterpret_cast<const double2_a16 *>(t + 2);
 		}
 #pragma unroll
 		for ( int u = 0; u < AU; u++ ) {
-		    const bool in = i0 + (uint32_t)u < cnt;
-		    const double Sr = in ? p0[u].x : 0.0, Si = in ? p0[u].y : 0.0;
-		    const double Tr = in ? p1[u].x : 0.0, Ti = in ? p1[u].y : 0.0;
+		    const double Sr = p0[u].x, Si = p0[u].y, Tr = p1[u].x, Ti = p1[u].y;
 		    // (Sr + i Si) (c + i m),  (c, m) = (cos, -sin) of the offset
 		    mr = fma(Sr, t0[u].x, mr);  mr = fma(-Si, t0[u].y, mr);
 		    mi = fma(Sr, t0[u].y, mi);  mi = fma(Si, t0[u].x, mi);
 		    sr = fma(Tr, t1[u].x, sr);  sr = fma(-Ti, t1[u].y, sr);
 		    si = fma(Tr, t1[u].y, si);  si = fma(Ti, t1[u].x, si);
-		    aw += in ? as[u] : 0.0f;
+		    aw += as[u];
 		}
 	    }
-	    const double delta = dscale * (double)aw;
+	    const double delta = dscale * sqrt((double)aw);
 	    const bool stable = (float)( mr - delta ) == (float)( mr + delta )
 			     && (float)( mi - delta ) == (float)( mi + delta )
 			     && (float)( sr - delta ) == (float)( sr + delta )
@@ -755,8 +776,8 @@ struct Wave {
 	    if ( !m )
 		continue;
 	    bump(21);
-	    wave_lds_sync();				// (the partials are not needed any more: their
-	    uint32_t *list = partRel;			//  space holds the list of windows)
+	    wave_lds_sync();				// (the partials are not needed any more: the tile
+	    uint32_t *list = plan_cache() + 2u * kPlanWords;	//  is a tile again; the windows' list sits behind the plan words)
 	    const uint32_t nredo = (uint32_t)__popcll(m);
 	    if ( ( m >> lane ) & 1ull )
 		list[__popcll(m & ( ( 1ull << lane ) - 1ull ))] = 64u * h + lane;
@@ -931,7 +952,7 @@ constexpr size_t kCntBytes = ( MIFSK_NCOUNTERS * sizeof(uint32_t) + 15u ) & ~(si
 // ST: the instantiation behind mifsk_demod_slab (state in, state out); the plain kernels do
 // not carry its code or its registers
 template <int SV, int NQ, bool ST = false>
-__global__ __launch_bounds__(64, SV >= 10 ? 2 : MIFSK_WAVE_OCC)
+__global__ __launch_bounds__(64, NQ == kTiled ? 3 : ( SV >= 10 ? 2 : MIFSK_WAVE_OCC ))
 void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restrict__ tw_default,
 	mifsk_demod_io io, WaveGeom g, WaveAuto au )
 {
@@ -1625,9 +1646,8 @@ bool plan_for( const DevCfg &cfg, const WaveHostArgs &ha, int sv, size_t budget,
 	    bool any = false;
 	    for ( int i = 0; i < 4; i++ )
 		any = any || cfg.seg[i].valid;
-	    if ( any )			// shared segments: partial sums [SEG_MAX] x (4 doubles, |x| sum, start)
-		sf += (size_t)SEG_MAX * ( 4u * sizeof(double) + 2u * sizeof(float) ) / sizeof(float)
-		    + 2u * ( 2u * SEG_MAX + SEG_MAX / 4u );	// ... and the carrier-held scans' plan words
+	    if ( any )			// shared segments: the carrier-held scans' plan words, the list of
+		sf += 2u * ( 2u * SEG_MAX + SEG_MAX / 4u ) + 64u;	// windows to sum again (the partial sums lie on the tile)
 	}
 	const size_t total = kCntBytes + (size_t)g.mags_cap * sizeof(float2) + sf * 4u + 16u;
 	if ( total <= budget ) {
@@ -1682,7 +1702,7 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
     // Long windows are better read through the tile at two waves per SIMD than
     // from a slab that leaves one wave per SIMD (tools/ubench/longwin.hip: 17 ms
     // against 45): a slab only while it fits 8 waves per CU then
-    const bool tile_ok = !ha.ring_exact && cfg.bit_nsamples >= 4u * TILE_K && force_sv != 4;
+    const bool tile_ok = !ha.ring_exact && cfg.bit_nsamples >= kTileMinBit && force_sv != 4;
     const uint32_t wmin = tile_ok ? 8u : 4u;
     for ( uint32_t wpc = want; wpc >= wmin && !ok; wpc -= ( wpc > 8u ? 4u : ( wpc > 4u ? 2u : 1u ) ) ) {
 	const size_t budget = ( kLdsPerCu / wpc ) & ~(size_t)255;
@@ -1701,8 +1721,9 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
 	// nothing keeps the SCAN slab in LDS (RTTY: 1056-sample windows, a 40 kB
 	// span; 0.5 baud: 96000-sample windows): the windows come from global
 	// memory through a 17 kB tile, two waves per SIMD
-	// (with the shared segments' partial sums behind the tile, seven waves per CU)
-	for ( uint32_t wpc = want < 8u ? want : 8u; wpc >= 4u && !ok; wpc-- ) {
+	// (three waves per SIMD by its registers; the tile and the shared segments' plan words
+	// are 12.4 kB)
+	for ( uint32_t wpc = want < 12u ? want : 12u; wpc >= 4u && !ok; wpc-- ) {
 	    const size_t budget = ( kLdsPerCu / wpc ) & ~(size_t)255;
 	    ok = plan_for(cfg, ha, 10, budget, plan, true) && plan.g.tiled;
 	}
@@ -1735,6 +1756,10 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
     au.d_state = ha.d_state;
     au.d_origin = ha.d_origin;
     au.final = ha.final ? 1u : 0u;
+    for ( int k = 0; k < 4; k++ ) {
+	au.d_rot[k] = ha.d_rot[k];
+	au.rot_stride[k] = ha.rot_stride[k];
+    }
 
     // the instantiation: staging width x resident-table correlator for the bit
     // lengths that have one (linear LATTICE only)
@@ -1748,7 +1773,7 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
 	plan_only->lds_bytes = (uint32_t)plan.lds_bytes;
 	plan_only->lattice_mode = g.lat_mode;
 	plan_only->frames_per_block = g.lat_mode != LAT_NONE ? g.lat_fmax : 0u;
-	plan_only->waves_per_simd = plan.sv == 10 ? 2u : 4u;
+	plan_only->waves_per_simd = g.tiled ? 3u : ( plan.sv == 10 ? 2u : 4u );
 	return 0;
     }
     hipStream_t st = (hipStream_t)stream;
