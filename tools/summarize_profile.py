@@ -44,8 +44,28 @@ def kernel_durations(path):
     return sum(d) / max(1, len(d)), len(d)
 
 
+def code_object_figures(kernel):
+    """The kernel's register / spill / scratch figures from the code object's own metadata
+    (profiles/<tag>_kernel_resources.txt, written by tools/kernel_resources.sh): rocprofv3's
+    VGPR_Count / LDS_Block_Size columns are launch-packet fields (granules, static LDS only) and
+    do not say what the kernel uses."""
+    import glob
+    import re
+    want = re.sub(r"\s+", "", kernel or "")
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_kernel_resources.txt")), reverse=True):
+        for line in open(path):
+            m = re.match(r"\S+\s+(.*?)\s+vgpr\s+(\d+)\s+agpr\s+(\d+)\s+vgpr_spill\s+(\d+)\s+sgpr\s+(\d+)"
+                         r"\s+sgpr_spill\s+(\d+)\s+scratch\s+(\d+) B", line)
+            name = re.sub(r"\s+", "", m.group(1)) if m else ""
+            if m and want in (name, name.replace(",false>", ">")):     # (the plan names the plain instantiation)
+                return {"vgpr": int(m.group(2)), "agpr": int(m.group(3)), "vgpr_spill": int(m.group(4)),
+                        "sgpr": int(m.group(5)), "sgpr_spill": int(m.group(6)), "scratch_bytes": int(m.group(7)),
+                        "source": os.path.relpath(path, ROOT)}
+    return None
+
+
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
     configs = sys.argv[2:] or ["1200"]
     dst = os.path.join(ROOT, "profiles")
     ksid = bench.kernel_source_id()
@@ -85,7 +105,12 @@ def main():
         json.dump({
             "kernel": info.get("kernel"), "workload": b["config"]["workload"],
             "kernel_source_id": ksid, "per_launch": dict(sq, **clk),
-            "dispatches_averaged": n, "launch": info, "derived": derived,
+            "dispatches_averaged": n,
+            # what was launched: rocprofv3's packet fields (its VGPR count is in allocation granules
+            # of the packet, its LDS the static part only), the code object's own metadata, and the
+            # library's plan (dynamic LDS per workgroup, workgroups per CU)
+            "launch": info, "code_object": code_object_figures(b["roofline"]["kernel"]),
+            "plan": b["roofline"].get("launch"), "derived": derived,
         }, open(os.path.join(dst, pre + "_sq_counters.json"), "w"), indent=1)
         with open(os.path.join(src, "stats_kernel_stats.csv")) as f:
             for r in csv.DictReader(f):
