@@ -75,11 +75,68 @@ def test_invalid_modes_rejected():
             O.oracle_config(**kw)
 
 
+def _declared_functions():
+    """every function name include/*.h declares (a declarator followed by `(` at the start of a
+    declaration: `int  mifsk_x( ...`, `const char *mifsk_y( ...`, `fsk_plan *` newline `fsk_z(`)"""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = set()
+    for h in ("fsk.h", "mifsk.h"):
+        text = open(os.path.join(root, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b((?:mifsk|fsk)_\w+)\s*\(", text))
+    return names - {"mifsk_h"}
+
+
 def test_library_exports_every_declared_symbol():
+    """The library loads and exports every symbol the two headers declare, and the binding's
+    list is that list (no compute calls: this runs without a GPU)."""
     lib = _lib.load()
-    for name in _lib.EXPORTS:
+    declared = _declared_functions()
+    assert len(declared) > 40
+    assert declared == set(_lib.EXPORTS), (declared ^ set(_lib.EXPORTS))
+    for name in sorted(declared):
         assert hasattr(lib, name), name
     assert lib.mifsk_abi_version() == 4
+
+
+def test_scan_plans_cover_their_windows():
+    """Shared-segment plans (host side, no GPU): every window of a long-window scan is tiled
+    exactly by consecutive segments, every segment sits in exactly one lane of one pass, the
+    packed copies say what the plain arrays say."""
+    import numpy as np
+    for mode, kw in (("rtty", {}), ("rtty", dict(sample_rate=44100)), ("50", {}), ("30", {}),
+                     ("rtty", dict(sample_rate=96000))):
+        cfg = M.rx_config(mode, **kw)
+        B, nb = int(cfg.bit_nsamples), int(cfg.expect_n_bits)
+        for kind in range(4):
+            p = M.scan_plan(cfg, kind)
+            assert p is not None, (mode, kw, kind)
+            first = cfg.try_first[kind & 1]
+            mx = cfg.try_max[kind & 1]
+            step = (cfg.try_step_fine if kind & 2 else cfg.try_step)[kind & 1]
+            U = (mx - first - 1) // step + 1
+            D = min(U - 1, first // step)
+            cands = [first] + [first + ((i + 1) // 2) * step if i & 1 else first - ((i + 1) // 2) * step
+                               for i in range(1, 2 * D + 1)] + [first + (i - D) * step for i in range(2 * D + 1, U + D)]
+            assert p["nwin"] == len(cands) * nb
+            rel, ln = p["seg_rel"].astype(np.int64), p["seg_len"].astype(np.int64)
+            assert np.all(np.diff(rel) >= ln[:-1])                     # position order, no overlap
+            for w in range(p["nwin"]):
+                a = cands[w // nb] + int(cfg.bit_offset[w % nb])
+                f, c = int(p["win_first"][w]), int(p["win_count"][w])
+                assert rel[f] == a and rel[f + c - 1] + ln[f + c - 1] == a + B
+                assert np.all(rel[f:f + c - 1] + ln[f:f + c - 1] == rel[f + 1:f + c])
+            slots = p["slot_seg"]
+            used = slots[slots != 0xFFFF]
+            assert sorted(used.tolist()) == list(range(p["nseg"]))     # each segment exactly once
+            for ps in range(p["npass"]):
+                mine = slots[64 * ps:64 * ps + 64]
+                mine = mine[mine != 0xFFFF]
+                assert ln[mine].max() == p["pass_len"][ps] and ln[mine].min() == p["pass_min"][ps]
+            assert p["bound_c"] >= B + 100
+    assert M.scan_plan(M.rx_config("1200"), 1) is None                  # short windows: no plan
 
 
 def test_struct_layouts_match_between_bindings():

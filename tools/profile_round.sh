@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 for C in $CONFIGS; do
   OUT=gpurun_out/profile_${TAG}_$C
   mkdir -p $OUT
-  B="python bench.py --config $C --no-cpu"
+  B="python bench.py --config $C --no-cpu --no-h2d"
   # 1. per-kernel time of the very command the bench line comes from
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o stats -- \
       $B --steps 20 --warmup 3 > $OUT/bench_under_rocprof.log 2>&1
