@@ -1735,6 +1735,33 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
 	if ( !ok )
 	    return -12;
     }
+    // Whole rounds.  A batch of more streams than waves fit runs in rounds, and a last round
+    // that is a fraction of one leaves the chip mostly idle while its chains finish (4096 RTTY
+    // streams at 12 waves per CU are 1.33 rounds: measured 13.8 ms against 13.3 at 8-10).  Among
+    // the occupancies this plan allows (down to two thirds of the most) take the one that wastes
+    // the fewest wave slots over the whole batch, the higher one on a tie; the kernel is limited
+    // to it by its LDS allocation.
+    {
+	const uint32_t by_lds = (uint32_t)( kLdsPerCu / ( plan.lds_bytes ? plan.lds_bytes : 1 ) );
+	const uint32_t by_regs = ( plan.g.tiled ? 3u : ( plan.sv == 10 ? 2u : 4u ) ) * 4u;
+	const uint32_t most = by_lds < by_regs ? by_lds : by_regs;
+	const uint32_t per_cu = ( (uint32_t)( io.nstreams > 0 ? io.nstreams : 0 ) + (uint32_t)ncu - 1u ) / (uint32_t)ncu;
+	if ( most >= 3u && per_cu > most ) {
+	    uint32_t best = most, best_waste = 0xFFFFFFFFu;
+	    for ( uint32_t w = most; 3u * w >= 2u * most; w-- ) {
+		const uint32_t waste = ( per_cu + w - 1u ) / w * w - per_cu;
+		if ( waste < best_waste ) {
+		    best_waste = waste;
+		    best = w;
+		}
+	    }
+	    if ( best < most ) {
+		const size_t pad = ( kLdsPerCu / best ) & ~(size_t)255;	// exactly `best` of these fit a CU
+		if ( pad > plan.lds_bytes && kLdsPerCu / pad == best )
+		    plan.lds_bytes = pad;
+	    }
+	}
+    }
     if ( const char *e = experiment_env("MIFSK_LDS_PAD") )	// experiments only: limit occupancy
 	if ( (size_t)std::atoi(e) > plan.lds_bytes )
 	    plan.lds_bytes = (size_t)std::atoi(e);

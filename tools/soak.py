@@ -19,11 +19,13 @@ import minimodem_amd as M    # noqa: E402
 MODES = [("1200", {}), ("300", {}), ("12000", {}), ("same", {}), ("rtty", {}), ("tdd", {}),
          ("1200", dict(n_data_bits=7)), ("1200", dict(msb_first=1)), ("2400", {}),
          ("1200", dict(sample_rate=44100)), ("600", dict(nstopbits=2.0)),
-         ("1200", dict(auto_carrier_threshold=0.001)), ("300", dict(auto_carrier_threshold=0.001))]
+         ("1200", dict(auto_carrier_threshold=0.001)), ("300", dict(auto_carrier_threshold=0.001)),
+         # long windows: SCAN with shared segments (wave engine), other bit lengths than RTTY's
+         ("rtty", dict(sample_rate=44100)), ("50", {}), ("rtty", dict(auto_carrier_threshold=0.001))]
 
 
 def make_stream(rng, cfg, mode):
-    slow = mode in ("rtty", "tdd")
+    slow = mode in ("rtty", "tdd", "50")
     nwords = int(rng.integers(1, 12 if slow else 120))
     hi = 1 << min(8, int(cfg.n_data_bits))
     words = rng.integers(0, hi, size=nwords, dtype=np.uint8)
