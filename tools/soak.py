@@ -58,6 +58,9 @@ def main():
     ap.add_argument("--streams", type=int, default=96)
     ap.add_argument("--engine", default="wave", choices=["wave", "workgroup"])
     ap.add_argument("--ring", action="store_true", help="RING addressing (wave engine), oracle ring_mode")
+    ap.add_argument("--slabs", type=int, default=0,
+                    help="feed every stream in this many pieces, cut at random places, through "
+                         "mifsk_demod_slab (SlabSession) instead of one mifsk_demod_batch call")
     args = ap.parse_args()
     import torch
     ctx = M.Context(0)
@@ -77,18 +80,42 @@ def main():
             host[i, :len(s)] = s
             lens[i] = len(s)
         t = time.time()
-        res = M.results_to_host(M.demod_batch(ctx, cfg, torch.from_numpy(host).cuda(),
-                                              nsamples=torch.from_numpy(lens).cuda(),
-                                              want=("bytes", "frames", "episodes"), episodes_cap=64,
-                                              engine=args.engine, ring_exact=args.ring))
+        if args.slabs:
+            # every stream cut at its own random places; the pieces' outputs concatenated
+            cuts = [sorted(int(c) for c in rng.integers(0, len(s) + 1, size=args.slabs - 1)) for s in streams]
+            sess = M.SlabSession(ctx, cfg, len(streams), episodes_cap=64)
+            acc = [dict(frames=[], episodes=[], bytes=b"") for _ in streams]
+            for k in range(args.slabs):
+                new = []
+                for i, s in enumerate(streams):
+                    e = [0] + cuts[i] + [len(s)]
+                    new.append(s[e[k]:e[k + 1]])
+                r = sess.feed(new, final=(k == args.slabs - 1))
+                for i in range(len(streams)):
+                    n, ne = int(r["nframes"][i]), int(r["nepisodes"][i])
+                    acc[i]["frames"].append(r["frames"][i, :n].copy())
+                    acc[i]["episodes"].append(r["episodes"][i, :ne].copy())
+                    acc[i]["bytes"] += r["bytes"][i, :int(r["nbytes"][i])].tobytes()
+        else:
+            res = M.results_to_host(M.demod_batch(ctx, cfg, torch.from_numpy(host).cuda(),
+                                                  nsamples=torch.from_numpy(lens).cuda(),
+                                                  want=("bytes", "frames", "episodes"), episodes_cap=64,
+                                                  engine=args.engine, ring_exact=args.ring))
         nf = 0
         for i, s in enumerate(streams):
             ref = O.oracle_rx_stream(ocfg, s, ring_mode=args.ring)
-            n, ne = int(res["nframes"][i]), int(res["nepisodes"][i])
-            ok = (n == len(ref["frames"]) and ne == len(ref["episodes"])
-                  and res["frames"][i, :n].tobytes() == ref["frames"].tobytes()
-                  and res["episodes"][i, :ne].tobytes() == ref["episodes"].tobytes()
-                  and res["bytes"][i, :int(res["nbytes"][i])].tobytes() == ref["bytes"])
+            if args.slabs:
+                fr = np.concatenate(acc[i]["frames"])
+                ep = np.concatenate(acc[i]["episodes"])
+                n, ne = len(fr), len(ep)
+                ok = (fr.tobytes() == ref["frames"].tobytes() and ep.tobytes() == ref["episodes"].tobytes()
+                      and acc[i]["bytes"] == ref["bytes"])
+            else:
+                n, ne = int(res["nframes"][i]), int(res["nepisodes"][i])
+                ok = (n == len(ref["frames"]) and ne == len(ref["episodes"])
+                      and res["frames"][i, :n].tobytes() == ref["frames"].tobytes()
+                      and res["episodes"][i, :ne].tobytes() == ref["episodes"].tobytes()
+                      and res["bytes"][i, :int(res["nbytes"][i])].tobytes() == ref["bytes"])
             if not ok:
                 bad += 1
                 print("MISMATCH mode %s %r stream %d (len %d): gpu %d frames, oracle %d"
@@ -96,8 +123,9 @@ def main():
             nf += n
         total_frames += nf
         print("%-6s %-40s %4d streams %7d frames  %.1f s" % (mode, kw, len(streams), nf, time.time() - t))
-    print("seed %d (%s engine, %s addressing): %d frames compared, %d mismatching streams"
-          % (args.seed, args.engine, "ring" if args.ring else "flat", total_frames, bad))
+    print("seed %d (%s engine, %s addressing%s): %d frames compared, %d mismatching streams"
+          % (args.seed, args.engine, "ring" if args.ring else "flat",
+             ", %d slabs per stream" % args.slabs if args.slabs else "", total_frames, bad))
     sys.exit(1 if bad else 0)
 
 
