@@ -33,22 +33,29 @@ namespace mifsk {
 // offsets are rounded, consecutive windows may leave a sample between them), split the
 // longest pieces until the lanes of ceil(n / 64) passes are full, hand the pieces to
 // the passes longest first.
-static void plan_segments( SegPlan &sp, const mifsk_rx_config &c, unsigned first, unsigned mx, unsigned step )
+// candidates of one zig-zag scan in scan order (fsk.c:477-484), appended to `out`
+static void zigzag_candidates( std::vector<unsigned> &out, unsigned first, unsigned mx, unsigned step )
 {
-    std::memset(&sp, 0, sizeof(sp));
-    const unsigned nb = c.expect_n_bits, B = c.bit_nsamples;
-    if ( (int)first >= (int)mx || step == 0 || nb == 0 )
+    if ( (int)first >= (int)mx || step == 0 )
 	return;
     const unsigned U = ( mx - first - 1 ) / step + 1;
     const unsigned D = U - 1 < first / step ? U - 1 : first / step;
-    const unsigned J = U + D;
-    if ( J * nb > (unsigned)SEGW_MAX )
+    for ( unsigned i = 0; i < U + D; i++ ) {
+	if ( i == 0 ) out.push_back(first);
+	else if ( i <= 2 * D ) out.push_back(( i & 1u ) ? first + ( ( i + 1 ) / 2 ) * step : first - ( ( i + 1 ) / 2 ) * step);
+	else out.push_back(first + ( i - D ) * step);
+    }
+}
+
+// `cand`: the candidates whose windows the plan covers, window w = candidate w / n_bits, bit w % n_bits
+static void plan_segments( SegPlan &sp, const mifsk_rx_config &c, const std::vector<unsigned> &cand )
+{
+    std::memset(&sp, 0, sizeof(sp));
+    const unsigned nb = c.expect_n_bits, B = c.bit_nsamples;
+    const unsigned J = (unsigned)cand.size();
+    if ( J == 0 || nb == 0 || J * nb > (unsigned)SEGW_MAX )
 	return;
-    auto at = [&]( unsigned i ) -> unsigned {
-	if ( i == 0 ) return first;
-	if ( i <= 2 * D ) return ( i & 1u ) ? first + ( ( i + 1 ) / 2 ) * step : first - ( ( i + 1 ) / 2 ) * step;
-	return first + ( i - D ) * step;
-    };
+    auto at = [&]( unsigned i ) -> unsigned { return cand[i]; };
     std::vector<unsigned> wstart(J * nb);
     std::vector<unsigned> cuts;
     for ( unsigned j = 0; j < J; j++ )
@@ -276,9 +283,19 @@ void fill_devcfg( DevCfg &d, const mifsk_rx_config &c )
     // long windows (what the wavefront engine reads through its LDS tile): the scans share
     // their segments' partial sums
     if ( c.bit_nsamples >= 256u && c.bit_nsamples <= 65535u )
-	for ( int i = 0; i < 4; i++ )
-	    plan_segments(d.seg[i], c, c.try_first[i & 1], c.try_max[i & 1],
-			  ( i & 2 ) ? c.try_step_fine[i & 1] : c.try_step[i & 1]);
+	for ( int i = 0; i < 4; i++ ) {
+	    std::vector<unsigned> cand;
+	    zigzag_candidates(cand, c.try_first[i & 1], c.try_max[i & 1],
+			      ( i & 2 ) ? c.try_step_fine[i & 1] : c.try_step[i & 1]);
+	    plan_segments(d.seg[i], c, cand);
+	}
+    if ( d.seg[1].valid && d.seg[3].valid ) {
+	std::vector<unsigned> cand;
+	zigzag_candidates(cand, c.try_first[1], c.try_max[1], c.try_step[1]);
+	d.seg_union_first_fine = (uint32_t)cand.size() * c.expect_n_bits;
+	zigzag_candidates(cand, c.try_first[1], c.try_max[1], c.try_step_fine[1]);
+	plan_segments(d.seg[4], c, cand);
+    }
     d.div_magic = c.bit_nsamples > 1 ? (uint32_t)( 0x100000000ULL / c.bit_nsamples ) : 0xFFFFFFFFu;
     // minimodem.c:1407 with frame_start == try_first (carrier)
     d.lock_advance = c.try_first[1] + c.frame_nsamples - c.nsamples_overscan;
@@ -473,7 +490,7 @@ static int get_devcfg( mifsk_ctx *ctx, const DevCfg &d, const DevCfg **d_out, Cf
     ce.host = d;
     ce.dev = dev;
     // shared segments: every window's rotation factors, [segment of the window][window]
-    for ( int k = 0; k < 4; k++ ) {
+    for ( int k = 0; k < 5; k++ ) {
 	ce.d_rot[k] = nullptr;
 	ce.rot_stride[k] = 0;
 	const mifsk::SegPlan &sp = d.seg[k];
@@ -612,7 +629,7 @@ static int demod_batch_wave( mifsk_ctx *ctx, const mifsk_rx_config *cfg, const D
     ha.final = final;
     // (--auto-carrier retunes per stream: its rotation factors come from the stream's own table)
     if ( tables && !( cfg->auto_carrier_threshold > 0.0f ) )
-	for ( int k = 0; k < 4; k++ ) {
+	for ( int k = 0; k < 5; k++ ) {
 	    ha.d_rot[k] = tables->d_rot[k];
 	    ha.rot_stride[k] = tables->rot_stride[k];
 	}
@@ -710,7 +727,7 @@ static_assert(sizeof(mifsk_scan_plan) == sizeof(mifsk::SegPlan), "mifsk_scan_pla
 
 extern "C" int mifsk_scan_plan_get( const mifsk_rx_config *cfg, int kind, mifsk_scan_plan *out )
 {
-    if ( mifsk_check_cfg(cfg) || !out || kind < 0 || kind > 3 )
+    if ( mifsk_check_cfg(cfg) || !out || kind < 0 || kind > 4 )
 	return -EINVAL;
     DevCfg *d = new (std::nothrow) DevCfg();
     if ( !d )

@@ -38,8 +38,8 @@ struct CfgEntry {
     DevCfg	host;
     DevCfg	*dev;
     // shared segments: rotation tables of the four scans (mifsk_device.h WaveAuto::d_rot)
-    double	*d_rot[4];
-    uint32_t	rot_stride[4];
+    double	*d_rot[5];
+    uint32_t	rot_stride[5];
 };
 
 struct mifsk_ctx {

@@ -88,8 +88,12 @@ struct DevCfg {
     uint64_t	req_mask[2];
     uint64_t	req_val[2];
     // shared-segment plans of the four scans (index as zz_up / zz_down); valid only for
-    // the long-window modes the tiled instantiation runs
-    SegPlan	seg[4];
+    // the long-window modes the tiled instantiation runs.  [4]: the carrier-held coarse scan
+    // and the fine scan that may follow it at the same cursor (minimodem.c:1265,1373) as ONE
+    // plan -- windows 0 .. nwin(1)-1 are the coarse scan's, the fine scan's follow: the span is
+    // read and summed once, the fine scan's windows are assembled from sums already there
+    SegPlan	seg[5];
+    uint32_t	seg_union_first_fine;	// [4]: index of the fine scan's first window
 };
 
 // twiddles: tw[4*n + {0,1,2,3}] = cos_mark, -sin_mark, cos_space, -sin_space
@@ -162,8 +166,8 @@ struct WaveAuto {
     // [i][w] so that the lanes of the assembly (lane = window) read consecutive entries:
     // d_rot[kind][(i * rot_stride[kind] + w) * 4 .. + 3] = table entry of the segment's offset
     // inside the window (NULL: gathered from the stream's own table -- --auto-carrier)
-    const double	*d_rot[4];
-    uint32_t		rot_stride[4];
+    const double	*d_rot[5];
+    uint32_t		rot_stride[5];
 };
 
 // what the host glue hands the launcher besides cfg / io
@@ -184,8 +188,8 @@ struct WaveHostArgs {
     mifsk_stream_state *d_state;
     const uint64_t *d_origin;
     bool	final;
-    const double *d_rot[4];
-    uint32_t	rot_stride[4];
+    const double *d_rot[5];
+    uint32_t	rot_stride[5];
 };
 
 int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_tw,

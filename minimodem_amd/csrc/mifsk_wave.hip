@@ -194,6 +194,10 @@ struct Wave {
     // just made, reusable by a rescan at the same cursor (scan())
     FrameOut		k0;
     bool		k0_valid;
+    // shared segments: the coarse + fine plan's partial sums for the search at this cursor
+    // are on the tile (nothing has used the tile since)
+    uint32_t		un_base = 0;
+    bool		un_valid = false;
     // register prefetch of the next LINEAR round
     float4		pbuf[SV];
     uint32_t		pref_lo;
@@ -414,6 +418,7 @@ struct Wave {
 	    const uint32_t ci = cfg.lat_grid ? lane * ( nb - 1u ) : lane * nb;
 	    fo = frame_confidence_any(&mags[ci], cfg.req_mask[0], cfg.req_val[0], nb);
 	}
+	un_valid = false;			// (a block's windows may have gone through the tile)
 	l_conf = fo.conf;
 	l_ampl = fo.ampl;
 	l_bits = fo.bits;
@@ -549,7 +554,9 @@ struct Wave {
     {
 	uint32_t *pc = plan_cache();
 	for ( uint32_t kc = 0; kc < 2u; kc++ ) {
-	    const SegPlan &sp = cfg.seg[2u * kc + 1u];
+	    // slot 0: what the carrier-held coarse scan runs (with the fine scan's windows in
+	    // it where there is such a plan), slot 1: the fine scan on its own
+	    const SegPlan &sp = cfg.seg[kc ? 3u : ( cfg.seg[4].valid ? 4u : 1u )];
 	    uint32_t *q = pc + kc * kPlanWords;
 	    for ( uint32_t i = lane; i < (uint32_t)SEG_MAX; i += 64u ) {
 		q[i] = sp.p_slot[i];
@@ -561,14 +568,20 @@ struct Wave {
 	wave_lds_sync();
     }
 
-    __device__ __forceinline__ void seg_correlate( uint32_t base, const ZigZag &zz, uint32_t c0 )
+    // pi: the plan (0..3 = the scan's own, 4 = coarse + fine in one); w_off: the plan's index of
+    // this scan's first window; with sum_it false the partial sums of the scan before (same
+    // plan, same cursor) are still on the tile and only the assembly runs.  Returns whether
+    // the partial sums are still there afterwards (no window had to be summed again).
+    __device__ __forceinline__ bool seg_correlate( uint32_t base, const ZigZag &zz, uint32_t c0,
+	    uint32_t pi, uint32_t w_off, bool sum_it )
     {
-	const uint32_t kind = zz.id & 3u;
+	const uint32_t kind = pi;
 	// (read where it is used, from the kernarg segment: KernArgs in mifsk_devlib.h)
 	const KernArgs<WaveArgs>::ptr ka = KernArgs<WaveArgs>::here();
 	const double *rot = ka->au.d_rot[kind];		// (uniform) NULL: gather from the stream's table
 	const uint32_t rstride = ka->au.rot_stride[kind];
 	const SegPlan &sp = cfg.seg[kind];
+	const uint32_t nwin_scan = zz.J * cfg.n_bits;	// this scan's windows: plan windows w_off ...
 	const uint32_t nb = cfg.n_bits, B = cfg.bit_nsamples;
 	// (one entry more than there can be segments: an all-zero partial sum, what the lanes
 	// of the assembly read once their own window's segments are used up)
@@ -578,10 +591,12 @@ struct Wave {
 	double *partD = reinterpret_cast<double *>(slab);			// [kParts][4]
 	float *partA = reinterpret_cast<float *>(partD + 4 * kParts);		// [kParts]
 	uint32_t *partRel = reinterpret_cast<uint32_t *>(partA + kParts);	// [kParts]
-	const bool cached = ( kind & 1u ) != 0u && cfg.seg[1].valid && cfg.seg[3].valid;
-	const uint32_t *pc = plan_cache() + ( kind >> 1 ) * kPlanWords;
+	const bool both = cfg.seg[1].valid && cfg.seg[3].valid;
+	const bool cached = both && ( kind == 3u || kind == ( cfg.seg[4].valid ? 4u : 1u ) );
+	const uint32_t *pc = plan_cache() + ( kind == 3u ? 1u : 0u ) * kPlanWords;
 	const uint32_t tg0 = MIFSK_WCLOCK();
 	const uint32_t np = sp.npass;
+	if ( sum_it ) {
 	// this lane's segment in each pass: start | length << 20, position index (0xFF: none)
 	uint32_t sw0, sw1, si0, si1;
 	if ( cached ) {
@@ -707,6 +722,7 @@ struct Wave {
 	}
 	wave_lds_sync();
 	bump(20);
+	}	// sum_it
 	const uint32_t tg1 = MIFSK_WCLOCK();
 	cyc_g_pass += tg1 - tg0;
 	// assemble: lane = window
@@ -714,11 +730,12 @@ struct Wave {
 	// are float sums: a little slack)
 	const double dscale = (double)sp.bound_c * 1.0001 * 1.1102230246251565e-16 * sqrt((double)B);
 	unsigned long long redo0 = 0ull, redo1 = 0ull;
-	for ( uint32_t g0 = 0; g0 < sp.nwin; g0 += 64u ) {
+	for ( uint32_t g0 = 0; g0 < nwin_scan; g0 += 64u ) {
 	    const uint32_t w = g0 + lane;
-	    const bool active = w < sp.nwin;
-	    const uint32_t ww = active ? w : 0u;
-	    const uint32_t j = udiv_magic(ww, nb, cfg.nbits_magic), k = ww - j * nb;
+	    const bool active = w < nwin_scan;
+	    const uint32_t wl = active ? w : 0u;		// the scan's window ...
+	    const uint32_t ww = w_off + wl;			// ... is this one of the plan
+	    const uint32_t j = udiv_magic(wl, nb, cfg.nbits_magic), k = wl - j * nb;
 	    const uint32_t pw = cached ? pc[SEG_MAX + ww] : sp.p_win[ww];
 	    const uint32_t first = pw & 0xFFu, cnt = ( pw >> 8 ) & 0xFFu, a_rel = pw >> 16;
 	    const uint32_t cmax = wave_max_u32(cnt);
@@ -793,6 +810,7 @@ struct Wave {
 	    wave_lds_sync();
 	}
 	cyc_g_redo += MIFSK_WCLOCK() - tg2;
+	return ( redo0 | redo1 ) == 0ull;
     }
 
     // `reuse0`: candidate 0 of this scan is the candidate 0 of the scan just made at
@@ -875,11 +893,28 @@ struct Wave {
 	    if constexpr ( NQ == kTiled ) {
 		// long windows, the whole (rest of the) scan in this chunk, far enough from the
 		// end of the stream that whole tile steps may be loaded behind every window
-		shared = g.tiled && !ring && zz.id < 4u && cfg.seg[zz.id & 3u].valid && c0 + Q == zz.J
-		      && base + cfg.seg[zz.id & 3u].span_hi + cfg.bit_nsamples + 192u <= N
-		      && base + cfg.seg[zz.id & 3u].span_hi + cfg.bit_nsamples + 192u >= base;
-		if ( shared )
-		    seg_correlate(base, zz, c0);
+		// The carrier-held coarse scan runs the plan that also holds the fine scan's windows
+		// (minimodem.c:1265 then :1373 at the same cursor): if the fine scan follows, the
+		// partial sums are still on the tile and only its windows' assembly is left.
+		uint32_t pi = zz.id & 3u, w_off = 0u;
+		bool sum_it = true;
+		if ( zz.id == 1u && cfg.seg[4].valid ) {
+		    pi = 4u;
+		} else if ( zz.id == 3u && cfg.seg[4].valid && un_valid && un_base == base ) {
+		    pi = 4u;
+		    w_off = cfg.seg_union_first_fine;
+		    sum_it = false;
+		}
+		shared = g.tiled && !ring && zz.id < 4u && cfg.seg[pi].valid && c0 + Q == zz.J
+		      && base + cfg.seg[pi].span_hi + cfg.bit_nsamples + 192u <= N
+		      && base + cfg.seg[pi].span_hi + cfg.bit_nsamples + 192u >= base;
+		if ( shared ) {
+		    const bool kept = seg_correlate(base, zz, c0, pi, w_off, sum_it);
+		    un_valid = kept && pi == 4u;
+		    un_base = base;
+		} else {
+		    un_valid = false;		// (the windows go through the tile one by one)
+		}
 	    }
 	    if ( !shared )
 		scan_correlate(base, zz, c0, Q, use_slab);
@@ -1783,7 +1818,7 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
     au.d_state = ha.d_state;
     au.d_origin = ha.d_origin;
     au.final = ha.final ? 1u : 0u;
-    for ( int k = 0; k < 4; k++ ) {
+    for ( int k = 0; k < 5; k++ ) {
 	au.d_rot[k] = ha.d_rot[k];
 	au.rot_stride[k] = ha.rot_stride[k];
     }

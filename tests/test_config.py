@@ -136,6 +136,19 @@ def test_scan_plans_cover_their_windows():
                 mine = mine[mine != 0xFFFF]
                 assert ln[mine].max() == p["pass_len"][ps] and ln[mine].min() == p["pass_min"][ps]
             assert p["bound_c"] >= B + 100
+        # the plan that holds the carrier-held coarse scan's windows AND the fine scan's (kind 4):
+        # coarse windows first, each tiled exactly by its segments
+        u = M.scan_plan(cfg, 4)
+        c1, c3 = M.scan_plan(cfg, 1), M.scan_plan(cfg, 3)
+        assert u is not None and u["nwin"] == c1["nwin"] + c3["nwin"]
+        urel, uln = u["seg_rel"].astype(np.int64), u["seg_len"].astype(np.int64)
+        for kind, off in ((1, 0), (3, c1["nwin"])):
+            pk = M.scan_plan(cfg, kind)
+            for w in range(pk["nwin"]):
+                a = int(pk["seg_rel"][pk["win_first"][w]])              # the window's start
+                f, c = int(u["win_first"][off + w]), int(u["win_count"][off + w])
+                assert urel[f] == a and urel[f + c - 1] + uln[f + c - 1] == a + B
+                assert np.all(urel[f:f + c - 1] + uln[f:f + c - 1] == urel[f + 1:f + c])
     assert M.scan_plan(M.rx_config("1200"), 1) is None                  # short windows: no plan
 
 
