@@ -1375,6 +1375,7 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 	    ctx.load_resident_twiddles();
 	    ctx.lat_n = 0;				// scored with the old tones
 	    ctx.slab_lo = ctx.slab_hi = 0;
+	    ctx.un_valid = false;			// (partial sums on the tile: made with the old tones)
 	}
 
 	if ( nvalid < cfg.expect_nsamples )			// :1229
