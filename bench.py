@@ -372,7 +372,7 @@ def run_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, cp
         value = total_samples * steps / dt
         kavg = float(np.mean(kernel_ms)) * 1e-3
         achieved = total_samples_local * 4.0 / kavg
-        launch = M.demod_plan(ctx, cfg, nstreams, engine=args.engine)	# what the library launches
+        launch = M.demod_plan(ctx, cfg, nstreams, engine=args.engine, nsamples=stride)	# what the library launches
         line = {
             "metric": "audio samples/sec demodulated (whole node), %s-baud 48 kHz f32"
                       % {"1200": "1200", "rtty": "45.45", "12000": "12000", "same": "520.83"}[name],

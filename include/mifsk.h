@@ -36,7 +36,7 @@ extern "C" {
 #endif
 
 #define MIFSK_MAX_FRAME_BITS	64	/* fsk.c:185-187,463 */
-#define MIFSK_ABI_VERSION	4
+#define MIFSK_ABI_VERSION	5
 
 /* which databits decoder main() would have selected (minimodem.c:549-553,
  * 675,820,856,866,892).  Decoding frame bits to text is O(1)/frame host work
@@ -292,10 +292,22 @@ typedef struct mifsk_launch_info {
     uint32_t	lattice_mode;		/* 0 none, 1 LDS-staged rounds, 2 streamed */
     uint32_t	frames_per_block;	/* LATTICE frames scored at once, at most */
     uint32_t	compute_units;
+    /* Chained launches: a flat-addressed wavefront-engine batch of more streams than the
+     * chip holds at once is cut into chain_groups groups of streams x chain_chunks time
+     * chunks, every (group, chunk) one launch of the resumable kernel, each group's chunks
+     * in order on a HIP stream of the context's -- so that the slots one group's
+     * stragglers leave are filled with another group's next chunk instead of staying
+     * empty until the round ends.  Same frames, bit for bit (mifsk_demod_slab's
+     * guarantee).  0 / 0: one launch. */
+    uint32_t	chain_groups, chain_chunks;
 } mifsk_launch_info;
 
 int mifsk_demod_plan( mifsk_ctx *ctx, const mifsk_rx_config *cfg, int nstreams,
 	unsigned flags, mifsk_launch_info *out );
+/* ... for rows of `nsamples` samples (mifsk_demod_io.nsamples): whether a batch is cut in
+ * time depends on how long its streams are (mifsk_demod_plan assumes long ones) */
+int mifsk_demod_plan_ex( mifsk_ctx *ctx, const mifsk_rx_config *cfg, int nstreams,
+	uint32_t nsamples, unsigned flags, mifsk_launch_info *out );
 
 /* ---- streams that start in host memory (SURVEY 8 d "H2D-inclusive") -------- */
 
@@ -378,7 +390,9 @@ typedef struct mifsk_stream_state {
     int32_t	carrier_band, first_band;
     uint32_t	b_mark, ep_b_mark;
     uint32_t	ep_first;
-    uint32_t	reserved[3];
+    uint32_t	nbytes_total;	/* bytes, episodes emitted by all calls so far    */
+    uint32_t	nepisodes_total;
+    uint32_t	status;		/* MIFSK_STREAM_* bits of all calls so far        */
 } mifsk_stream_state;
 
 #define MIFSK_STATE_STARTED	1u

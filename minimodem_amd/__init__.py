@@ -206,14 +206,17 @@ def demod_batch(ctx, cfg, samples, nsamples=None, want=("bytes", "episodes"),
     return out
 
 
-def demod_plan(ctx, cfg, nstreams, ring_exact=False, engine=None):
-    """mifsk_demod_plan: what demod_batch would launch (kernel instantiation, engine,
-    workgroup size, dynamic LDS per workgroup, workgroups per CU by LDS, LATTICE mode)."""
+def demod_plan(ctx, cfg, nstreams, ring_exact=False, engine=None, nsamples=None):
+    """mifsk_demod_plan[_ex]: what demod_batch would launch (kernel instantiation, engine,
+    workgroup size, dynamic LDS per workgroup, workgroups per CU by LDS, LATTICE mode, and --
+    for rows of `nsamples` samples; None: long ones -- the groups x time chunks a large batch
+    is cut into)."""
     info = _lib.LaunchInfo()
     flags = (_lib.IO_RING_EXACT if ring_exact else 0) | \
         (_lib.IO_ENGINE_WORKGROUP if engine == "workgroup" else 0) | \
         (_lib.IO_ENGINE_WAVE if engine == "wave" else 0)
-    rc = _lib.load().mifsk_demod_plan(ctx.handle, C.byref(cfg), int(nstreams), flags, C.byref(info))
+    rc = _lib.load().mifsk_demod_plan_ex(ctx.handle, C.byref(cfg), int(nstreams),
+                                         0xFFFFFFFF if nsamples is None else int(nsamples), flags, C.byref(info))
     if rc != 0:
         raise RuntimeError("mifsk_demod_plan failed: %d" % rc)
     d = {k: getattr(info, k) for k, _ in info._fields_}
@@ -700,7 +703,8 @@ STATE_DTYPE = np.dtype([("base", "<u8"), ("rp", "<u8"), ("carrier_nsamples", "<u
                         ("nframes_decoded", "<u4"), ("noconfidence", "<u4"),
                         ("track_amplitude", "<f4"), ("peak_confidence", "<f4"),
                         ("carrier_band", "<i4"), ("first_band", "<i4"), ("b_mark", "<u4"),
-                        ("ep_b_mark", "<u4"), ("ep_first", "<u4"), ("reserved", "<u4", (3,))])
+                        ("ep_b_mark", "<u4"), ("ep_first", "<u4"), ("nbytes_total", "<u4"),
+                        ("nepisodes_total", "<u4"), ("status", "<u4")])
 assert STATE_DTYPE.itemsize == 96
 STATE_FINISHED = 4
 

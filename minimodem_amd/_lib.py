@@ -143,6 +143,7 @@ class LaunchInfo(C.Structure):
         ("lds_bytes_per_workgroup", C.c_uint32), ("workgroups_per_cu", C.c_uint32),
         ("lattice_mode", C.c_uint32), ("frames_per_block", C.c_uint32),
         ("compute_units", C.c_uint32),
+        ("chain_groups", C.c_uint32), ("chain_chunks", C.c_uint32),
     ]
 
 
@@ -201,7 +202,7 @@ EXPORTS = [
     "fsk_set_tones_by_bandshift",
     "mifsk_modem_args_default", "mifsk_rx_config_init", "mifsk_max_frames",
     "mifsk_stream_padding", "mifsk_ctx_create", "mifsk_ctx_destroy",
-    "mifsk_ctx_device_name", "mifsk_abi_version", "mifsk_find_frame_batch",
+    "mifsk_ctx_device_name", "mifsk_abi_version", "mifsk_find_frame_batch", "mifsk_demod_plan_ex",
     "mifsk_demod_batch", "mifsk_demod_batch_host",
     "mifsk_tx_tone_init", "mifsk_tx_synthesize",
     "mifsk_databits_create", "mifsk_databits_destroy", "mifsk_databits_reset",
@@ -291,6 +292,9 @@ def load():
     lib.mifsk_demod_plan.restype = C.c_int
     lib.mifsk_demod_plan.argtypes = [C.c_void_p, C.POINTER(RxConfig), C.c_int, C.c_uint,
                                      C.POINTER(LaunchInfo)]
+    lib.mifsk_demod_plan_ex.restype = C.c_int
+    lib.mifsk_demod_plan_ex.argtypes = [C.c_void_p, C.POINTER(RxConfig), C.c_int, C.c_uint32, C.c_uint,
+                                        C.POINTER(LaunchInfo)]
     lib.mifsk_demod_batch_host_multi.restype = C.c_int
     lib.mifsk_demod_batch_host_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(RxConfig),
                                                  C.POINTER(DemodIO)]

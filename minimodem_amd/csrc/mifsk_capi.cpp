@@ -401,6 +401,17 @@ extern "C" void mifsk_ctx_destroy( mifsk_ctx *ctx )
     }
     if ( ctx->host )
 	mifsk::host_work_destroy(ctx->host);
+    if ( ctx->chain_made ) {
+	for ( void *st : ctx->chain.streams )
+	    if ( st ) {
+		(void)hipStreamSynchronize((hipStream_t)st);
+		(void)hipStreamDestroy((hipStream_t)st);
+	    }
+	for ( void *e : ctx->chain.ev_done )
+	    if ( e ) (void)hipEventDestroy((hipEvent_t)e);
+	if ( ctx->chain.ev_fork ) (void)hipEventDestroy((hipEvent_t)ctx->chain.ev_fork);
+	if ( ctx->chain.d_state ) (void)hipFree(ctx->chain.d_state);
+    }
     delete ctx;
 }
 
@@ -607,6 +618,42 @@ static bool use_workgroup_engine( const mifsk_rx_config *cfg, const DevCfg &d, u
     return workgroup;
 }
 
+// What a chained launch needs (mifsk_device.h WaveChain), with room for `ns` streams' states.
+// Called with ctx->chain_lock held.
+static int chain_prepare( mifsk_ctx *ctx, size_t ns )
+{
+    mifsk::WaveChain &ch = ctx->chain;
+    if ( !ctx->chain_made ) {
+	for ( void *&st : ch.streams ) {
+	    hipStream_t h = nullptr;
+	    HIP_OK(hipStreamCreateWithFlags(&h, hipStreamNonBlocking));
+	    st = h;
+	}
+	hipEvent_t e = nullptr;
+	HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+	ch.ev_fork = e;
+	for ( void *&d : ch.ev_done ) {
+	    HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+	    d = e;
+	}
+	ctx->chain_made = true;
+    }
+    if ( ns > ch.state_cap ) {
+	// (the chain before may still be running on the old array)
+	for ( void *st : ch.streams )
+	    HIP_OK(hipStreamSynchronize((hipStream_t)st));
+	if ( ch.d_state )
+	    (void)hipFree(ch.d_state);
+	ch.d_state = nullptr;
+	ch.state_cap = 0;
+	const size_t cap = ( ns + 1023 ) & ~(size_t)1023;
+	if ( hipMalloc((void **)&ch.d_state, cap * sizeof(mifsk_stream_state)) != hipSuccess )
+	    return -ENOMEM;
+	ch.state_cap = cap;
+    }
+    return 0;
+}
+
 // One wavefront per stream (mifsk_wave.hip): --auto-carrier and RING addressing
 // need per-call device scratch; it is allocated and freed in stream order, so
 // concurrent calls on different streams never share it.
@@ -627,6 +674,10 @@ static int demod_batch_wave( mifsk_ctx *ctx, const mifsk_rx_config *cfg, const D
     ha.d_state = d_state;
     ha.d_origin = d_origin;
     ha.final = final;
+    // a whole-stream call over a plain batch may be cut into chained launches (the launcher
+    // decides by the batch's shape)
+    ha.chain_ok = !d_state && !( io->flags & MIFSK_IO_RING_EXACT ) && !( cfg->auto_carrier_threshold > 0.0f )
+	       && !io->d_counters;
     // (--auto-carrier retunes per stream: its rotation factors come from the stream's own table)
     if ( tables && !( cfg->auto_carrier_threshold > 0.0f ) )
 	for ( int k = 0; k < 5; k++ ) {
@@ -675,7 +726,21 @@ static int demod_batch_wave( mifsk_ctx *ctx, const mifsk_rx_config *cfg, const D
 	}
 	ha.d_ring = (float *)scratch_ring;
     }
-    const int rc = mifsk::launch_demod_wave(d, d_cfg, d_tw, *io, ha, stream);
+    int rc;
+    if ( ha.chain_ok ) {
+	mifsk::LaunchInfo li;
+	std::memset(&li, 0, sizeof(li));
+	rc = mifsk::launch_demod_wave(d, d_cfg, d_tw, *io, ha, stream, &li);
+	if ( rc == 0 && li.chain_groups ) {
+	    std::lock_guard<std::mutex> one(ctx->chain_lock);
+	    rc = chain_prepare(ctx, ns);
+	    if ( rc )
+		return rc;
+	    ha.chain = &ctx->chain;
+	    return mifsk::launch_demod_wave(d, d_cfg, d_tw, *io, ha, stream);
+	}
+    }
+    rc = mifsk::launch_demod_wave(d, d_cfg, d_tw, *io, ha, stream);
     if ( scratch_tw ) (void)hipFreeAsync(scratch_tw, st);
     if ( scratch_ring ) (void)hipFreeAsync(scratch_ring, st);
     return rc;
@@ -774,6 +839,12 @@ extern "C" int mifsk_demod_slab( mifsk_ctx *ctx, const mifsk_rx_config *cfg, con
 extern "C" int mifsk_demod_plan( mifsk_ctx *ctx, const mifsk_rx_config *cfg, int nstreams,
 	unsigned flags, mifsk_launch_info *out )
 {
+    return mifsk_demod_plan_ex(ctx, cfg, nstreams, 0xFFFFFFFFu, flags, out);
+}
+
+extern "C" int mifsk_demod_plan_ex( mifsk_ctx *ctx, const mifsk_rx_config *cfg, int nstreams,
+	uint32_t nsamples, unsigned flags, mifsk_launch_info *out )
+{
     if ( !ctx || !out || mifsk_check_cfg(cfg) || nstreams < 0 )
 	return -EINVAL;
     DevCfg d;
@@ -781,6 +852,7 @@ extern "C" int mifsk_demod_plan( mifsk_ctx *ctx, const mifsk_rx_config *cfg, int
     mifsk_demod_io io;
     std::memset(&io, 0, sizeof(io));
     io.nstreams = nstreams;
+    io.nsamples = nsamples;
     io.flags = flags;
     mifsk::LaunchInfo li;
     std::memset(&li, 0, sizeof(li));
@@ -802,6 +874,8 @@ extern "C" int mifsk_demod_plan( mifsk_ctx *ctx, const mifsk_rx_config *cfg, int
     out->lattice_mode = li.lattice_mode;
     out->frames_per_block = li.frames_per_block;
     out->compute_units = (uint32_t)ctx->ncu;
+    out->chain_groups = li.chain_groups;
+    out->chain_chunks = li.chain_chunks;
     return 0;
 }
 

@@ -59,6 +59,12 @@ struct mifsk_ctx {
     // (the spectrum table of fsk_detect_carrier is a TwEntry with bit_nsamples == 0)
     // the host-memory pipeline's streams, events and pinned staging (mifsk_hostpipe.cpp)
     mifsk::HostWork	*host = nullptr;
+    // chained launches (mifsk_device.h WaveChain): the groups' streams and events and the state
+    // array, made at the first batch that is cut; one chain is enqueued at a time (chain_lock),
+    // and each waits for the one before on the device (ev_done)
+    std::mutex		chain_lock;
+    mifsk::WaveChain	chain = {};
+    bool		chain_made = false;
 };
 
 #define HIP_OK(call)	do { hipError_t e_ = (call); if ( e_ != hipSuccess ) { \

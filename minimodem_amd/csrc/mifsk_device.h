@@ -123,6 +123,7 @@ struct LaunchInfo {
     uint32_t	lattice_mode;		// LAT_*
     uint32_t	frames_per_block;	// LATTICE frames scored at once, at most
     uint32_t	waves_per_simd;		// what the instantiation is compiled for (its VGPR budget)
+    uint32_t	chain_groups, chain_chunks;	// chained launches (WaveChain): groups of streams x time chunks; 0 = one launch
 };
 
 int launch_demod_batch( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_tw,
@@ -162,12 +163,30 @@ struct WaveAuto {
     mifsk_stream_state	*d_state;
     const uint64_t	*d_origin;	// stream index of each row's first sample (NULL: 0)
     uint32_t		final;		// the rows end where the streams end
+    uint32_t		limit;		// chained launches: this call sees the first `limit` samples of
+					// every row (a row that ends before is complete); 0 = all
     // shared segments: the rotation factor of segment i of window w of scan `kind`, laid out
     // [i][w] so that the lanes of the assembly (lane = window) read consecutive entries:
     // d_rot[kind][(i * rot_stride[kind] + w) * 4 .. + 3] = table entry of the segment's offset
     // inside the window (NULL: gathered from the stream's own table -- --auto-carrier)
     const double	*d_rot[5];
     uint32_t		rot_stride[5];
+    uint32_t		append;		// outputs continue behind the call before (state: n*_total)
+};
+
+// Chained launches.  A batch of more streams than the chip holds runs in rounds of serial
+// chains of unequal length: while a round's stragglers finish, the slots the others left stay
+// empty.  Cut in time instead -- G groups of streams x K chunks of every stream, each (group,
+// chunk) one launch of the resumable kernel, a group's chunks in order on the group's own HIP
+// stream -- the dispatcher fills those slots with the other groups' next chunk, and the idle
+// tail shrinks to that of one chunk.  The context owns what this needs (mifsk_capi.cpp).
+struct WaveChain {
+    enum { kMaxGroups = 3 };
+    void		*streams[kMaxGroups];	// hipStream_t, non-blocking
+    void		*ev_fork;		// hipEvent_t: the caller's stream at the call
+    void		*ev_done[kMaxGroups];	// ... and each group's last chunk
+    mifsk_stream_state	*d_state;		// [state_cap] the loop's state between chunks
+    size_t		state_cap;
 };
 
 // what the host glue hands the launcher besides cfg / io
@@ -190,6 +209,10 @@ struct WaveHostArgs {
     bool	final;
     const double *d_rot[5];
     uint32_t	rot_stride[5];
+    // non-NULL: the launcher may chain (it decides by the batch's shape); the caller holds
+    // whatever serialises the chain's users.  chain_ok: what a plan-only call assumes
+    const WaveChain *chain;
+    bool	chain_ok;
 };
 
 int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_tw,

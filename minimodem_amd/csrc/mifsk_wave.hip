@@ -46,6 +46,7 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -756,7 +757,10 @@ struct Wave {
 		    const uint32_t d = in ? partRel[s] - a_rel : 0u;	// offset of the segment inside the window
 		    // its rotation factor: from the scan's own table, laid out for this loop (lanes
 		    // read side by side), or entry d of the stream's table
-		    const double *t = rot ? rot + 4 * ( (size_t)i * rstride + ww ) : tw + 4 * (size_t)d;
+		    // (beyond its own segments a lane multiplies the zero entry: by a factor that exists --
+		    // row i of the rotation table may lie behind the table's end, and 0 x whatever bits
+		    // are there could be NaN)
+		    const double *t = rot ? rot + 4 * ( (size_t)( in ? i : 0u ) * rstride + ww ) : tw + 4 * (size_t)d;
 		    t0[u] = *reinterpret_cast<const double2_a16 *>(t);
 		    t1[u] = *reinterpret_cast<const double2_a16 *>(t + 2);
 		}
@@ -987,7 +991,7 @@ constexpr size_t kCntBytes = ( MIFSK_NCOUNTERS * sizeof(uint32_t) + 15u ) & ~(si
 // ST: the instantiation behind mifsk_demod_slab (state in, state out); the plain kernels do
 // not carry its code or its registers
 template <int SV, int NQ, bool ST = false>
-__global__ __launch_bounds__(64, NQ == kTiled ? 3 : ( SV >= 10 ? 2 : MIFSK_WAVE_OCC ))
+__global__ __launch_bounds__(64, NQ == kTiled ? 2 : ( SV >= 10 ? 2 : MIFSK_WAVE_OCC ))
 void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restrict__ tw_default,
 	mifsk_demod_io io, WaveGeom g, WaveAuto au )
 {
@@ -1021,6 +1025,14 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
     float *ring = g.ring_exact ? au.d_ring + (size_t)s * g.ring_stride : nullptr;
     if ( ring )
 	lattice_ok = false;			// RING addressing: every frame through the general path
+    // chained launches (launch_demod_wave): this call takes the stream up to au.limit only
+    bool cut = false;
+    if constexpr ( ST ) {
+	if ( au.d_state && au.limit != 0u && au.limit < N ) {
+	    N = au.limit;
+	    cut = true;
+	}
+    }
     const double *tw = tw_default;
     double *tw_own = nullptr;
     if ( g.autodetect ) {
@@ -1070,7 +1082,7 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
     // Positions inside the kernel are relative to the row; what leaves it (frame starts,
     // episode frame indices, the saved state) counts from the start of the stream.
     const bool stateful = ST && au.d_state != nullptr;
-    const bool last_slab = !stateful || au.final != 0u;
+    const bool last_slab = !stateful || au.final != 0u || ( au.limit != 0u && !cut );
     uint64_t origin = 0;
     uint32_t frame_base = 0;			// frames emitted by the calls before
     bool resumable = true;
@@ -1102,6 +1114,14 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 		ep_b_mark = st.ep_b_mark;
 		ep_first = st.ep_first;
 		frame_base = (uint32_t)st.nframes_total;
+		if ( au.append ) {
+		    // the outputs continue where the call before stopped instead of at index 0
+		    n_out_frames = frame_base;
+		    n_out_bytes = st.nbytes_total;
+		    n_out_eps = st.nepisodes_total;
+		    status = st.status;
+		    frame_base = 0u;
+		}
 		if ( g.autodetect && carrier_band >= 0 ) {	// the tones found before: this stream's table again
 		    wave_build_table(tw_own, au.d_cs, (uint32_t)carrier_band,
 				     (uint32_t)( carrier_band + g.b_shift ), cfg.bit_nsamples, g.fftsize, g.tw_entries);
@@ -1524,7 +1544,11 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 	st.b_mark = b_mark;
 	st.ep_b_mark = ep_b_mark;
 	st.ep_first = ep_first;
-	st.reserved[0] = st.reserved[1] = st.reserved[2] = 0;
+	// (totals: read back rather than carried through the loop)
+	const uint32_t b0 = au.append ? 0u : au.d_state[s].nbytes_total, e0 = au.append ? 0u : au.d_state[s].nepisodes_total;
+	st.nbytes_total = b0 + n_out_bytes;
+	st.nepisodes_total = e0 + n_out_eps;
+	st.status = au.d_state[s].status | status;
 	au.d_state[s] = st;
     }
     if ( carrier && !paused && resumable ) {			// minimodem.c:1469-1474
@@ -1541,7 +1565,8 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 	}
 	n_out_eps++;
     }
-    if ( t0 ) {
+    // (append: a stream the call before finished keeps the outputs that call wrote)
+    if ( t0 && !( ST && au.append != 0u && !resumable && status == 0u ) ) {
 	if ( n_out_frames > o.fcap && ( o.bits || o.frames || o.bytes ) )
 	    status |= MIFSK_STREAM_FRAMES_TRUNCATED;
 	if ( n_out_eps > o.ecap && o.eps )
@@ -1756,10 +1781,11 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
     if ( !ok && force_sv != 4 ) {
 	// nothing keeps the SCAN slab in LDS (RTTY: 1056-sample windows, a 40 kB
 	// span; 0.5 baud: 96000-sample windows): the windows come from global
-	// memory through a 17 kB tile, two waves per SIMD
-	// (three waves per SIMD by its registers; the tile and the shared segments' plan words
-	// are 12.4 kB)
-	for ( uint32_t wpc = want < 12u ? want : 12u; wpc >= 4u && !ok; wpc-- ) {
+	// memory through the tile (with the shared segments' plan words 12.9 kB), two waves per
+	// SIMD: compiled for three (168 VGPRs) the instantiation spilled 44 VGPRs to scratch and
+	// ran 4096 RTTY streams in 10.8 ms at 8 waves per CU; with 191 VGPRs and nothing spilled
+	// the same 8 waves per CU take 9.3 ms (profiles/r03_history.md)
+	for ( uint32_t wpc = want < 8u ? want : 8u; wpc >= 4u && !ok; wpc-- ) {
 	    const size_t budget = ( kLdsPerCu / wpc ) & ~(size_t)255;
 	    ok = plan_for(cfg, ha, 10, budget, plan, true) && plan.g.tiled;
 	}
@@ -1771,18 +1797,48 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
 	if ( !ok )
 	    return -12;
     }
+    // Chained launches (WaveChain, mifsk_device.h): where the plain instantiation is one of the
+    // resumable ones, the batch is more than the chip holds at once and the streams are long
+    // enough to cut (a chunk's last samplebuf waits for the next chunk: at least 8 per chunk).
+    uint32_t chain_g = 0, chain_k = 0;
+    {
+	const uint32_t nq0 = ( plan.g.lat_mode == LAT_LINEAR && cfg.bit_nsamples % 4u == 0u ) ? cfg.bit_nsamples / 4u : 0u;
+	const bool st_kernel = plan.g.tiled || !( ( plan.sv == 10 && ( nq0 == 10u || nq0 == 5u ) ) || ( plan.sv == 4 && nq0 == 1u ) );
+	const uint32_t by_lds = (uint32_t)( kLdsPerCu / ( plan.lds_bytes ? plan.lds_bytes : 1 ) );
+	const uint32_t by_regs = ( plan.g.tiled || plan.sv == 10 ? 2u : 4u ) * 4u;
+	const uint64_t slots = (uint64_t)( by_lds < by_regs ? by_lds : by_regs ) * (uint64_t)ncu;
+	const bool allowed = ( plan_only ? ha.chain_ok : ha.chain != nullptr ) && st_kernel && !ha.d_state
+			  && !ha.ring_exact && !ha.autodetect && !io.d_counters && io.nstreams > 0;
+	if ( allowed && (uint64_t)io.nstreams > slots && ha.samplebuf_size > 0u ) {
+	    chain_g = 2u;
+	    chain_k = io.nsamples / ( 8u * ha.samplebuf_size );
+	    if ( chain_k > 8u ) chain_k = 8u;
+	}
+	if ( const char *e = experiment_env("MIFSK_CHAIN") ) {	// experiments and tests only: "G,K", any batch
+	    int a = 0, b = 0;
+	    if ( allowed && std::sscanf(e, "%d,%d", &a, &b) == 2 ) {
+		chain_g = (uint32_t)( a < 0 ? 0 : a );
+		chain_k = (uint32_t)( b < 0 ? 0 : b );
+	    }
+	}
+	if ( chain_g > (uint32_t)WaveChain::kMaxGroups ) chain_g = (uint32_t)WaveChain::kMaxGroups;
+	if ( chain_g > (uint32_t)io.nstreams ) chain_g = (uint32_t)io.nstreams;
+	if ( chain_g < 1u || chain_k < 2u )
+	    chain_g = chain_k = 0u;
+    }
     // Whole rounds.  A batch of more streams than waves fit runs in rounds, and a last round
     // that is a fraction of one leaves the chip mostly idle while its chains finish (4096 RTTY
     // streams at 12 waves per CU are 1.33 rounds: measured 13.8 ms against 13.3 at 8-10).  Among
     // the occupancies this plan allows (down to two thirds of the most) take the one that wastes
     // the fewest wave slots over the whole batch, the higher one on a tie; the kernel is limited
-    // to it by its LDS allocation.
+    // to it by its LDS allocation.  (Not for chained launches: their slots are refilled as they
+    // come free.)
     {
 	const uint32_t by_lds = (uint32_t)( kLdsPerCu / ( plan.lds_bytes ? plan.lds_bytes : 1 ) );
-	const uint32_t by_regs = ( plan.g.tiled ? 3u : ( plan.sv == 10 ? 2u : 4u ) ) * 4u;
+	const uint32_t by_regs = ( plan.g.tiled || plan.sv == 10 ? 2u : 4u ) * 4u;
 	const uint32_t most = by_lds < by_regs ? by_lds : by_regs;
 	const uint32_t per_cu = ( (uint32_t)( io.nstreams > 0 ? io.nstreams : 0 ) + (uint32_t)ncu - 1u ) / (uint32_t)ncu;
-	if ( most >= 3u && per_cu > most ) {
+	if ( most >= 3u && per_cu > most && !chain_g ) {
 	    uint32_t best = most, best_waste = 0xFFFFFFFFu;
 	    for ( uint32_t w = most; 3u * w >= 2u * most; w-- ) {
 		const uint32_t waste = ( per_cu + w - 1u ) / w * w - per_cu;
@@ -1819,6 +1875,8 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
     au.d_state = ha.d_state;
     au.d_origin = ha.d_origin;
     au.final = ha.final ? 1u : 0u;
+    au.limit = 0u;
+    au.append = 0u;
     for ( int k = 0; k < 5; k++ ) {
 	au.d_rot[k] = ha.d_rot[k];
 	au.rot_stride[k] = ha.rot_stride[k];
@@ -1836,10 +1894,85 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
 	plan_only->lds_bytes = (uint32_t)plan.lds_bytes;
 	plan_only->lattice_mode = g.lat_mode;
 	plan_only->frames_per_block = g.lat_mode != LAT_NONE ? g.lat_fmax : 0u;
-	plan_only->waves_per_simd = g.tiled ? 3u : ( plan.sv == 10 ? 2u : 4u );
+	plan_only->waves_per_simd = g.tiled || plan.sv == 10 ? 2u : 4u;
+	plan_only->chain_groups = chain_g;
+	plan_only->chain_chunks = chain_k;
 	return 0;
     }
     hipStream_t st = (hipStream_t)stream;
+    if ( chain_g ) {
+	const WaveChain &ch = *ha.chain;
+	if ( (size_t)io.nstreams > ch.state_cap )
+	    return -12;
+	const void *fn = g.tiled ? reinterpret_cast<const void *>(&demod_wave_kernel<10, kTiled, true>)
+		       : plan.sv == 10 ? reinterpret_cast<const void *>(&demod_wave_kernel<10, 0, true>)
+				       : reinterpret_cast<const void *>(&demod_wave_kernel<4, 0, true>);
+	if ( hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes) != hipSuccess )
+	    return -5;
+	hipEvent_t fork = (hipEvent_t)ch.ev_fork;
+	if ( hipEventRecord(fork, st) != hipSuccess )
+	    return -5;
+	mifsk_demod_io gio[WaveChain::kMaxGroups];
+	uint32_t glo[WaveChain::kMaxGroups];
+	for ( uint32_t gi = 0; gi < chain_g; gi++ ) {
+	    hipStream_t gs = (hipStream_t)ch.streams[gi];
+	    // behind the caller's stream, and behind whatever the call before left on ANY group's
+	    // stream (its groups were other ranges of the state array)
+	    (void)hipStreamWaitEvent(gs, fork, 0);
+	    for ( uint32_t h = 0; h < (uint32_t)WaveChain::kMaxGroups; h++ )
+		if ( h != gi )
+		    (void)hipStreamWaitEvent(gs, (hipEvent_t)ch.ev_done[h], 0);
+	    const uint32_t lo = (uint32_t)( (uint64_t)io.nstreams * gi / chain_g );
+	    const uint32_t hi = (uint32_t)( (uint64_t)io.nstreams * ( gi + 1u ) / chain_g );
+	    glo[gi] = lo;
+	    mifsk_demod_io &o = gio[gi];
+	    o = io;
+	    o.nstreams = (int)( hi - lo );
+	    o.d_samples = io.d_samples + (size_t)lo * io.stream_stride;
+	    if ( io.d_nsamples ) o.d_nsamples = io.d_nsamples + lo;
+	    if ( io.d_bytes ) o.d_bytes = io.d_bytes + (size_t)lo * io.frames_cap;
+	    if ( io.d_nbytes ) o.d_nbytes = io.d_nbytes + lo;
+	    if ( io.d_bits ) o.d_bits = io.d_bits + (size_t)lo * io.frames_cap;
+	    if ( io.d_frames ) o.d_frames = io.d_frames + (size_t)lo * io.frames_cap;
+	    if ( io.d_nframes ) o.d_nframes = io.d_nframes + lo;
+	    if ( io.d_episodes ) o.d_episodes = io.d_episodes + (size_t)lo * io.episodes_cap;
+	    if ( io.d_nepisodes ) o.d_nepisodes = io.d_nepisodes + lo;
+	    if ( io.d_status ) o.d_status = io.d_status + lo;
+	    if ( io.d_carrier_band ) o.d_carrier_band = io.d_carrier_band + lo;
+	    if ( o.nstreams > 0
+		    && hipMemsetAsync(ch.d_state + lo, 0, (size_t)o.nstreams * sizeof(mifsk_stream_state), gs) != hipSuccess )
+		return -5;
+	}
+	const uint32_t chunk = ( io.nsamples + chain_k - 1u ) / chain_k;
+	au.append = 1u;
+	au.d_origin = nullptr;
+	for ( uint32_t k = 0; k < chain_k; k++ ) {
+	    const bool last = k + 1u == chain_k;
+	    au.final = last ? 1u : 0u;
+	    au.limit = last ? 0u : ( k + 1u ) * chunk;
+	    for ( uint32_t gi = 0; gi < chain_g; gi++ ) {
+		if ( gio[gi].nstreams <= 0 )
+		    continue;
+		hipStream_t gs = (hipStream_t)ch.streams[gi];
+		au.d_state = ch.d_state + glo[gi];
+		if ( g.tiled )
+		    hipLaunchKernelGGL((demod_wave_kernel<10, kTiled, true>), dim3((unsigned)gio[gi].nstreams), dim3(64),
+				       plan.lds_bytes, gs, d_cfg, d_tw, gio[gi], g, au);
+		else if ( plan.sv == 10 )
+		    hipLaunchKernelGGL((demod_wave_kernel<10, 0, true>), dim3((unsigned)gio[gi].nstreams), dim3(64),
+				       plan.lds_bytes, gs, d_cfg, d_tw, gio[gi], g, au);
+		else
+		    hipLaunchKernelGGL((demod_wave_kernel<4, 0, true>), dim3((unsigned)gio[gi].nstreams), dim3(64),
+				       plan.lds_bytes, gs, d_cfg, d_tw, gio[gi], g, au);
+	    }
+	}
+	const bool launched = hipGetLastError() == hipSuccess;
+	for ( uint32_t gi = 0; gi < chain_g; gi++ ) {
+	    (void)hipEventRecord((hipEvent_t)ch.ev_done[gi], (hipStream_t)ch.streams[gi]);
+	    (void)hipStreamWaitEvent(st, (hipEvent_t)ch.ev_done[gi], 0);
+	}
+	return launched ? 0 : -5;
+    }
 #define MIFSK_WAVE_LAUNCH_ST(SV_, NQ_)										\
     do {													\
 	const void *fn = reinterpret_cast<const void *>(&demod_wave_kernel<SV_, NQ_, true>);			\

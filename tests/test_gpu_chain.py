@@ -1,0 +1,104 @@
+"""Chained launches (mifsk_launch_info.chain_groups / chain_chunks): a batch cut
+into groups of streams x time chunks, every (group, chunk) one launch of the resumable kernel,
+must give the frames, bytes and episodes of the single launch -- i.e. the oracle's -- whatever the
+cut.  The cut is forced onto small batches here (MIFSK_EXPERIMENT + MIFSK_CHAIN = "G,K": the
+library itself only cuts batches of more streams than the chip holds)."""
+import numpy as np
+import pytest
+
+import _golden as G
+import _oracle as O
+from test_gpu_parity import assert_stream_equal, run_gpu_streams
+
+pytestmark = pytest.mark.gpu
+
+CUTS = ["2,3", "1,5", "3,7"]
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    import minimodem_amd as M
+    assert torch.cuda.is_available(), "these tests need a real MI355X"
+    ctx = M.Context()
+    yield M, torch, ctx
+    ctx.close()
+
+
+def _chained(M, ctx, cfg, n, nsamples):
+    p = M.demod_plan(ctx, cfg, n, engine="wave", nsamples=nsamples)
+    return p["chain_groups"], p["chain_chunks"]
+
+
+@pytest.mark.parametrize("cut", CUTS)
+@pytest.mark.parametrize("name", G.names())
+def test_chained_launches_give_the_oracles_streams_on_goldens(gpu, monkeypatch, name, cut):
+    M, torch, ctx = gpu
+    g = G.load(name)
+    cfg = M.rx_config(**g["cfg_kwargs"])
+    if cfg.auto_carrier_threshold > 0:
+        pytest.skip("--auto-carrier batches are not cut")
+    x = g["samples"]
+    if len(x) > 2_000_000:
+        pytest.skip("one long stream: covered by the slab tests")
+    streams = [x, x[:int(len(x) * 0.61)], x[int(len(x) * 0.13):], x]
+    monkeypatch.setenv("MIFSK_EXPERIMENT", "1")
+    monkeypatch.setenv("MIFSK_CHAIN", cut)
+    groups, chunks = _chained(M, ctx, cfg, len(streams), (len(x) + 3) & ~3)
+    if not groups:
+        pytest.skip("this mode's kernel instantiation has no resumable twin (its batches are never cut)")
+    assert (groups, chunks) == tuple(int(v) for v in cut.split(","))
+    res = run_gpu_streams(M, torch, ctx, cfg, streams, engine="wave")
+    ocfg = O.oracle_config(**g["cfg_kwargs"])
+    for i, s in enumerate(streams):
+        assert_stream_equal(res, i, O.oracle_rx_stream(ocfg, s), "%s cut %s" % (name, cut))
+
+
+@pytest.mark.parametrize("mode,opts", [("rtty", {}), ("300", {}), ("same", {}), ("110", {})])
+def test_chained_equals_single_launch_on_noisy_ragged_batch(gpu, monkeypatch, mode, opts):
+    M, torch, ctx = gpu
+    cfg = M.rx_config(mode, **opts)
+    ocfg = O.oracle_config(mode, **opts)
+    rng = np.random.default_rng(77)
+    streams = []
+    for i in range(10):
+        nwords = int(rng.integers(20, 60))
+        five = cfg.n_data_bits == 5
+        words = rng.integers(0 if five else 32, 32 if five else 127, size=nwords).astype(np.uint8)
+        x = M.synthesize(cfg, words, amplitude=0.7, leading_silence=int(rng.integers(0, 3000)))
+        x = np.concatenate([x, np.zeros(int(rng.integers(0, 5000)), np.float32)])
+        x = x + rng.normal(0, [0.0, 0.05, 0.2, 0.5][i % 4], len(x)).astype(np.float32)
+        streams.append(x.astype(np.float32))
+    monkeypatch.setenv("MIFSK_EXPERIMENT", "1")
+    monkeypatch.setenv("MIFSK_CHAIN", "0,0")
+    single = run_gpu_streams(M, torch, ctx, cfg, streams, engine="wave")
+    stride = (max(len(s) for s in streams) + 3) & ~3
+    for cut in ("2,4", "3,9"):
+        monkeypatch.setenv("MIFSK_CHAIN", cut)
+        if not _chained(M, ctx, cfg, len(streams), stride)[0]:
+            pytest.skip("no resumable twin for this mode's instantiation")
+        res = run_gpu_streams(M, torch, ctx, cfg, streams, engine="wave")
+        for key in ("nframes", "nbytes", "nepisodes", "status"):
+            assert np.array_equal(res[key], single[key]), (mode, cut, key)
+        for i in range(len(streams)):
+            nf, nb, ne = int(single["nframes"][i]), int(single["nbytes"][i]), int(single["nepisodes"][i])
+            assert res["frames"][i, :nf].tobytes() == single["frames"][i, :nf].tobytes(), (mode, cut, i)
+            assert res["bytes"][i, :nb].tobytes() == single["bytes"][i, :nb].tobytes()
+            assert res["episodes"][i, :ne].tobytes() == single["episodes"][i, :ne].tobytes()
+    for i in (0, 3, 7):
+        assert_stream_equal(res, i, O.oracle_rx_stream(ocfg, streams[i]), mode)
+
+
+def test_which_batches_are_cut(gpu):
+    """The library's own rule: flat wavefront-engine batches of more streams than the chip holds
+    at once, streams long enough to cut, an instantiation with a resumable twin."""
+    M, torch, ctx = gpu
+    rtty = M.rx_config("rtty")
+    n = int(30 * rtty.sample_rate)
+    p = M.demod_plan(ctx, rtty, 4096, nsamples=n)
+    assert (p["chain_groups"], p["chain_chunks"]) == (2, 8) and p["kernel"].endswith("<10, -1>")
+    assert M.demod_plan(ctx, rtty, 1024, nsamples=n)["chain_groups"] == 0		# one round: nothing to fill
+    assert M.demod_plan(ctx, rtty, 4096, nsamples=8 * rtty.samplebuf_size)["chain_groups"] == 0	# too short
+    assert M.demod_plan(ctx, rtty, 4096, nsamples=n, ring_exact=True)["chain_groups"] == 0
+    # (12000 baud runs demod_wave_kernel<4, 1>: the resumable instantiations are the generic ones)
+    assert M.demod_plan(ctx, M.rx_config("12000"), 8192, nsamples=96000)["chain_groups"] == 0
