@@ -44,7 +44,7 @@ def kernel_durations(path):
     return sum(d) / max(1, len(d)), len(d)
 
 
-def code_object_figures(kernel):
+def code_object_figures(kernel, resumable=False):
     """The kernel's register / spill / scratch figures from the code object's own metadata
     (profiles/<tag>_kernel_resources.txt, written by tools/kernel_resources.sh): rocprofv3's
     VGPR_Count / LDS_Block_Size columns are launch-packet fields (granules, static LDS only) and
@@ -57,7 +57,9 @@ def code_object_figures(kernel):
             m = re.match(r"\S+\s+(.*?)\s+vgpr\s+(\d+)\s+agpr\s+(\d+)\s+vgpr_spill\s+(\d+)\s+sgpr\s+(\d+)"
                          r"\s+sgpr_spill\s+(\d+)\s+scratch\s+(\d+) B", line)
             name = re.sub(r"\s+", "", m.group(1)) if m else ""
-            if m and want in (name, name.replace(",false>", ">")):     # (the plan names the plain instantiation)
+            # (the plan names the plain instantiation; chained launches run its resumable twin)
+            if m and want == (name.replace(",true>", ">") if resumable else name.replace(",false>", ">")) \
+                    and (name.endswith(",true>") == resumable or "demod_wave" not in name):
                 return {"vgpr": int(m.group(2)), "agpr": int(m.group(3)), "vgpr_spill": int(m.group(4)),
                         "sgpr": int(m.group(5)), "sgpr_spill": int(m.group(6)), "scratch_bytes": int(m.group(7)),
                         "source": os.path.relpath(path, ROOT)}
@@ -77,9 +79,14 @@ def main():
             shutil.copy(os.path.join(src, a), os.path.join(dst, "%s_%s" % (pre, b)))
         b = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
         alg = b["roofline"]["algorithmic_bytes_per_launch"]
+        # chained launches: one pass over the batch is groups x chunks dispatches
+        # of the resumable kernel -- per-pass counters are the dispatch mean times that many
+        plan = b["roofline"].get("launch") or {}
+        groups, chunks = int(plan.get("chain_groups") or 0), int(plan.get("chain_chunks") or 0)
+        per = groups * chunks if groups else 1
         fetch, n, info = counters(os.path.join(src, "fetch_counter_collection.csv"))
         write, _, _ = counters(os.path.join(src, "write_counter_collection.csv"))
-        fkb, wkb = fetch["FETCH_SIZE"], write["WRITE_SIZE"]
+        fkb, wkb = fetch["FETCH_SIZE"] * per, write["WRITE_SIZE"] * per
         hbm = fkb * 1024.0 * 2.0 + wkb * 1024.0
         json.dump({
             "workload": b["config"]["workload"], "kernel": info.get("kernel"),
@@ -90,33 +97,38 @@ def main():
             "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of wide "
                     "coalesced reads); WRITE_SIZE uncalibrated (small); separate rocprofv3 --pmc passes, "
                     "--kernel-trace only",
-            "dispatches_averaged": n, "traffic_over_algorithmic": hbm / alg,
+            "dispatches_averaged": n, "dispatches_per_pass": per, "traffic_over_algorithmic": hbm / alg,
         }, open(os.path.join(dst, pre + "_hbm_traffic.json"), "w"), indent=1)
         sq, n, info = counters(os.path.join(src, "sq_counter_collection.csv"))
         clk, _, _ = counters(os.path.join(src, "clk_counter_collection.csv"))
+        sq = {k: v * per for k, v in sq.items()}
+        clk = {k: v * per for k, v in clk.items()}
         dur_ns, nd = kernel_durations(os.path.join(src, "clk_kernel_trace.csv"))
         samples = alg / 4.0
         derived = {"valu_insts_per_input_sample": sq["SQ_INSTS_VALU"] / samples,
                    "valu_wave_insts_per_launch": sq["SQ_INSTS_VALU"]}
         if "GRBM_GUI_ACTIVE" in clk and dur_ns:
             # GRBM_GUI_ACTIVE is summed over the 8 XCDs
-            derived["shader_clock_ghz_during_kernel"] = clk["GRBM_GUI_ACTIVE"] / 8.0 / dur_ns
-            derived["kernel_us_in_that_pass"] = dur_ns / 1e3
+            # (counter passes serialise the dispatches: a pass is `per` dispatches back to back)
+            derived["shader_clock_ghz_during_kernel"] = clk["GRBM_GUI_ACTIVE"] / 8.0 / (dur_ns * per)
+            derived["kernel_us_in_that_pass"] = dur_ns * per / 1e3
         json.dump({
             "kernel": info.get("kernel"), "workload": b["config"]["workload"],
             "kernel_source_id": ksid, "per_launch": dict(sq, **clk),
-            "dispatches_averaged": n,
+            "dispatches_averaged": n, "dispatches_per_pass": per,
             # what was launched: rocprofv3's packet fields (its VGPR count is in allocation granules
             # of the packet, its LDS the static part only), the code object's own metadata, and the
             # library's plan (dynamic LDS per workgroup, workgroups per CU)
-            "launch": info, "code_object": code_object_figures(b["roofline"]["kernel"]),
+            "launch": info, "code_object": code_object_figures(b["roofline"]["kernel"], resumable=groups > 0),
             "plan": b["roofline"].get("launch"), "derived": derived,
         }, open(os.path.join(dst, pre + "_sq_counters.json"), "w"), indent=1)
         with open(os.path.join(src, "stats_kernel_stats.csv")) as f:
             for r in csv.DictReader(f):
                 if is_demod(r["Name"]):
-                    print("%s: rocprofv3 --stats: %s calls, average %.1f us (bench.py events: %.1f us)"
-                          % (c, r["Calls"], float(r["AverageNs"]) / 1e3, b["roofline"]["kernel_ms_avg"] * 1e3))
+                    print("%s: rocprofv3 --stats: %s: %s calls, average %.1f us (bench.py events: %.1f us per pass%s)"
+                          % (c, r["Name"][:48], r["Calls"], float(r["AverageNs"]) / 1e3, b["roofline"]["kernel_ms_avg"] * 1e3,
+                             "; a pass is %d x %d dispatches, the %d groups' overlapping: average x %d = %.1f us"
+                             % (groups, chunks, groups, chunks, float(r["AverageNs"]) / 1e3 * chunks) if groups else ""))
         print("%s: HBM bytes/launch %.3e = %.2f x algorithmic; VALU wave-insts/launch %.3e; frac %.3f"
               % (c, hbm, hbm / alg, sq["SQ_INSTS_VALU"], b["roofline"]["frac"]))
 
