@@ -61,11 +61,14 @@ def main():
     ap.add_argument("--slabs", type=int, default=0,
                     help="feed every stream in this many pieces, cut at random places, through "
                          "mifsk_demod_slab (SlabSession) instead of one mifsk_demod_batch call")
+    ap.add_argument("--chain", action="store_true",
+                    help="force chained launches (MIFSK_EXPERIMENT, MIFSK_CHAIN = a random groups x "
+                         "chunks cut per configuration) onto these small batches: wave engine, flat")
     args = ap.parse_args()
     import torch
     ctx = M.Context(0)
     rng = np.random.default_rng(args.seed)
-    total_frames = bad = 0
+    total_frames = bad = chained = 0
     for mode, kw in MODES:
         if args.engine == "workgroup" and kw.get("auto_carrier_threshold"):
             continue                    # --auto-carrier runs on the wavefront engine only
@@ -80,6 +83,13 @@ def main():
             host[i, :len(s)] = s
             lens[i] = len(s)
         t = time.time()
+        cut = ""
+        if args.chain:
+            os.environ["MIFSK_EXPERIMENT"] = "1"
+            os.environ["MIFSK_CHAIN"] = "%d,%d" % (int(rng.integers(1, 4)), int(rng.integers(2, 12)))
+            p = M.demod_plan(ctx, cfg, len(streams), engine=args.engine, ring_exact=args.ring, nsamples=stride)
+            cut = " cut %dx%d" % (p["chain_groups"], p["chain_chunks"]) if p["chain_groups"] else " (not cut)"
+            chained += 1 if p["chain_groups"] else 0
         if args.slabs:
             # every stream cut at its own random places; the pieces' outputs concatenated
             cuts = [sorted(int(c) for c in rng.integers(0, len(s) + 1, size=args.slabs - 1)) for s in streams]
@@ -122,10 +132,11 @@ def main():
                       % (mode, kw, i, len(s), n, len(ref["frames"])))
             nf += n
         total_frames += nf
-        print("%-6s %-40s %4d streams %7d frames  %.1f s" % (mode, kw, len(streams), nf, time.time() - t))
+        print("%-6s %-40s %4d streams %7d frames  %.1f s%s" % (mode, kw, len(streams), nf, time.time() - t, cut))
     print("seed %d (%s engine, %s addressing%s): %d frames compared, %d mismatching streams"
           % (args.seed, args.engine, "ring" if args.ring else "flat",
-             ", %d slabs per stream" % args.slabs if args.slabs else "", total_frames, bad))
+             ", %d slabs per stream" % args.slabs if args.slabs else
+             ", %d configurations chained" % chained if args.chain else "", total_frames, bad))
     sys.exit(1 if bad else 0)
 
 
