@@ -1886,7 +1886,10 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
     // lengths that have one (linear LATTICE only)
     const uint32_t nq = ( g.lat_mode == LAT_LINEAR && cfg.bit_nsamples % 4u == 0u ) ? cfg.bit_nsamples / 4u : 0u;
     if ( plan_only ) {
-	plan_only->kernel = g.tiled ? "mifsk::demod_wave_kernel<10, -1>"
+	plan_only->kernel = chain_g ? ( g.tiled ? "mifsk::demod_wave_kernel<10, -1, true>"
+					 : plan.sv == 10 ? "mifsk::demod_wave_kernel<10, 0, true>"
+							 : "mifsk::demod_wave_kernel<4, 0, true>" )
+			  : g.tiled ? "mifsk::demod_wave_kernel<10, -1>"
 			  : plan.sv == 10 ? ( nq == 10u ? "mifsk::demod_wave_kernel<10, 10>"
 					   : nq == 5u ? "mifsk::demod_wave_kernel<10, 5>" : "mifsk::demod_wave_kernel<10, 0>" )
 					  : ( nq == 1u ? "mifsk::demod_wave_kernel<4, 1>" : "mifsk::demod_wave_kernel<4, 0>" );

@@ -96,7 +96,7 @@ def test_which_batches_are_cut(gpu):
     rtty = M.rx_config("rtty")
     n = int(30 * rtty.sample_rate)
     p = M.demod_plan(ctx, rtty, 4096, nsamples=n)
-    assert (p["chain_groups"], p["chain_chunks"]) == (2, 8) and p["kernel"].endswith("<10, -1>")
+    assert (p["chain_groups"], p["chain_chunks"]) == (2, 8) and p["kernel"].endswith("<10, -1, true>")
     assert M.demod_plan(ctx, rtty, 1024, nsamples=n)["chain_groups"] == 0		# one round: nothing to fill
     assert M.demod_plan(ctx, rtty, 4096, nsamples=8 * rtty.samplebuf_size)["chain_groups"] == 0	# too short
     assert M.demod_plan(ctx, rtty, 4096, nsamples=n, ring_exact=True)["chain_groups"] == 0

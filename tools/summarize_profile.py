@@ -44,7 +44,7 @@ def kernel_durations(path):
     return sum(d) / max(1, len(d)), len(d)
 
 
-def code_object_figures(kernel, resumable=False):
+def code_object_figures(kernel):
     """The kernel's register / spill / scratch figures from the code object's own metadata
     (profiles/<tag>_kernel_resources.txt, written by tools/kernel_resources.sh): rocprofv3's
     VGPR_Count / LDS_Block_Size columns are launch-packet fields (granules, static LDS only) and
@@ -57,9 +57,9 @@ def code_object_figures(kernel, resumable=False):
             m = re.match(r"\S+\s+(.*?)\s+vgpr\s+(\d+)\s+agpr\s+(\d+)\s+vgpr_spill\s+(\d+)\s+sgpr\s+(\d+)"
                          r"\s+sgpr_spill\s+(\d+)\s+scratch\s+(\d+) B", line)
             name = re.sub(r"\s+", "", m.group(1)) if m else ""
-            # (the plan names the plain instantiation; chained launches run its resumable twin)
-            if m and want == (name.replace(",true>", ">") if resumable else name.replace(",false>", ">")) \
-                    and (name.endswith(",true>") == resumable or "demod_wave" not in name):
+            # (the plan names the instantiation without a trailing ", false"; chained launches
+            # run the resumable twin, named in full)
+            if m and want in (name, name.replace(",false>", ">")):
                 return {"vgpr": int(m.group(2)), "agpr": int(m.group(3)), "vgpr_spill": int(m.group(4)),
                         "sgpr": int(m.group(5)), "sgpr_spill": int(m.group(6)), "scratch_bytes": int(m.group(7)),
                         "source": os.path.relpath(path, ROOT)}
@@ -119,7 +119,7 @@ def main():
             # what was launched: rocprofv3's packet fields (its VGPR count is in allocation granules
             # of the packet, its LDS the static part only), the code object's own metadata, and the
             # library's plan (dynamic LDS per workgroup, workgroups per CU)
-            "launch": info, "code_object": code_object_figures(b["roofline"]["kernel"], resumable=groups > 0),
+            "launch": info, "code_object": code_object_figures(b["roofline"]["kernel"]),
             "plan": b["roofline"].get("launch"), "derived": derived,
         }, open(os.path.join(dst, pre + "_sq_counters.json"), "w"), indent=1)
         with open(os.path.join(src, "stats_kernel_stats.csv")) as f:
