@@ -223,12 +223,11 @@ int launch_detect_carrier( const float *d_samples, unsigned nsamples,
 	float *d_mags /* [nbands] */, void *stream );
 
 // Tuning overrides for experiments (MIFSK_ENGINE, MIFSK_WAVES_PER_CU, MIFSK_SV,
-// MIFSK_LDS_PAD, MIFSK_LAT_ROUNDS): honoured only when MIFSK_EXPERIMENT is set in the
+// MIFSK_LDS_PAD, MIFSK_LAT_ROUNDS, MIFSK_CHAIN): honoured only when MIFSK_EXPERIMENT is set in the
 // environment, so that a stray variable cannot change what production launches.
 inline const char *experiment_env( const char *name )
 {
-    static const bool on = std::getenv("MIFSK_EXPERIMENT") != nullptr;
-    return on ? std::getenv(name) : nullptr;
+    return std::getenv("MIFSK_EXPERIMENT") != nullptr ? std::getenv(name) : nullptr;
 }
 
 // the HIP device a context is bound to (mifsk_capi.cpp)
