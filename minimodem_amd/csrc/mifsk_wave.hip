@@ -1138,7 +1138,7 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
     bool paused = false;
 
 
-    uint32_t cyc_bulk = 0, cyc_general = 0;
+    uint32_t cyc_bulk = 0, cyc_general = 0, cyc_b_replay = 0, cyc_b_out = 0;
     const uint32_t t_start = MIFSK_WCLOCK();
 #ifdef MIFSK_PROFILE
     const uint32_t t_wall0 = (uint32_t)wall_clock64();
@@ -1210,6 +1210,7 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 		// (minimodem.c:1357): the frame is an ordinary one whose only side
 		// effect is the reset of the running peak -- replayed as such.
 		const bool soft = cfg.try_step[1] <= 1u;
+		const uint32_t t_rp = MIFSK_WCLOCK();
 		float xt = ( track_amplitude + av ) / 2.0f;		// minimodem.c:1391
 		float xpk = peak_confidence < cv ? cv : peak_confidence;	// :1392-1393
 		if ( soft && cv < peak_confidence * 0.75f )
@@ -1242,6 +1243,8 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 		} else if ( e0 + K == ctx.lat_n ) {	// a whole block held: speculate further
 		    ctx.spec = 2u * ctx.spec < g.lat_fmax ? 2u * ctx.spec : g.lat_fmax;
 		}
+		const uint32_t t_out = MIFSK_WCLOCK();
+		cyc_b_replay += t_out - t_rp;
 		if ( n ) {
 		    float track, peak, ctot, atot;
 		    if ( n == K ) {
@@ -1311,6 +1314,7 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 			rp += N - rp < half ? N - rp : half;
 		    ctx.bump(MIFSK_CNT_BULK_FRAMES, n);
 		    progressed = true;
+		    cyc_b_out += MIFSK_WCLOCK() - t_out;
 		}
 	    }
 	    cyc_bulk += MIFSK_WCLOCK() - t_bulk;	// (block evaluation included)
@@ -1593,6 +1597,10 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 	    c[17] = ctx.cyc_s_stage;
 	    c[18] = ctx.cyc_s_corr;
 	    c[19] = ctx.cyc_s_conf;
+	    if ( NQ != kTiled ) {		// (profile build: replay and outputs of the bulk path)
+		c[20] = cyc_b_replay;
+		c[21] = cyc_b_out;
+	    }
 
 #ifdef MIFSK_PROFILE
 	    // when this stream started and ended on the chip-wide 100 MHz clock
