@@ -990,7 +990,9 @@ constexpr size_t kCntBytes = ( MIFSK_NCOUNTERS * sizeof(uint32_t) + 15u ) & ~(si
 #endif
 // ST: the instantiation behind mifsk_demod_slab (state in, state out); the plain kernels do
 // not carry its code or its registers
-template <int SV, int NQ, bool ST = false>
+// RA: the instantiation that can do RING addressing and --auto-carrier; the plain ones do not
+// carry that code or the registers it keeps alive either
+template <int SV, int NQ, bool ST = false, bool RA = true>
 __global__ __launch_bounds__(64, NQ == kTiled ? 2 : ( SV >= 10 ? 2 : MIFSK_WAVE_OCC ))
 void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restrict__ tw_default,
 	mifsk_demod_io io, WaveGeom g, WaveAuto au )
@@ -1022,7 +1024,8 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 	lattice_ok = false;
 	safe_limit = Wave<SV, NQ>::kRoundFloats;
     }
-    float *ring = g.ring_exact ? au.d_ring + (size_t)s * g.ring_stride : nullptr;
+    float *ring = ( RA && g.ring_exact ) ? au.d_ring + (size_t)s * g.ring_stride : nullptr;
+    const bool autodetect = RA && g.autodetect;
     if ( ring )
 	lattice_ok = false;			// RING addressing: every frame through the general path
     // chained launches (launch_demod_wave): this call takes the stream up to au.limit only
@@ -1035,7 +1038,7 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
     }
     const double *tw = tw_default;
     double *tw_own = nullptr;
-    if ( g.autodetect ) {
+    if ( autodetect ) {
 	tw_own = au.d_tw_scratch + (size_t)s * g.tw_entries * 4u;
 	tw = tw_own;
     }
@@ -1122,7 +1125,7 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 		    status = st.status;
 		    frame_base = 0u;
 		}
-		if ( g.autodetect && carrier_band >= 0 ) {	// the tones found before: this stream's table again
+		if ( autodetect && carrier_band >= 0 ) {	// the tones found before: this stream's table again
 		    wave_build_table(tw_own, au.d_cs, (uint32_t)carrier_band,
 				     (uint32_t)( carrier_band + g.b_shift ), cfg.bit_nsamples, g.fftsize, g.tw_entries);
 		    ctx.load_resident_twiddles();
@@ -1370,7 +1373,7 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 	if ( nvalid == 0 )					// :1176
 	    break;
 
-	if ( g.autodetect && carrier_band < 0 ) {		// :1179-1220
+	if ( autodetect && carrier_band < 0 ) {		// :1179-1220
 	    uint32_t i = 0;
 	    const float nps = g.nps;
 	    int band = -1;
@@ -1580,7 +1583,7 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 	if ( a->io.d_nbytes ) a->io.d_nbytes[s] = n_out_bytes;
 	if ( a->io.d_nepisodes ) a->io.d_nepisodes[s] = n_out_eps;
 	if ( a->io.d_status ) a->io.d_status[s] = status;
-	if ( a->io.d_carrier_band && a->g.autodetect ) a->io.d_carrier_band[s] = first_band;
+	if ( RA && a->io.d_carrier_band && a->g.autodetect ) a->io.d_carrier_band[s] = first_band;
 	if ( a->io.d_counters ) {
 	    uint64_t *c = a->io.d_counters + (size_t)s * MIFSK_NCOUNTERS;
 	    for ( int i = 0; i < MIFSK_NCOUNTERS; i++ )
@@ -1915,9 +1918,9 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
 	const WaveChain &ch = *ha.chain;
 	if ( (size_t)io.nstreams > ch.state_cap )
 	    return -12;
-	const void *fn = g.tiled ? reinterpret_cast<const void *>(&demod_wave_kernel<10, kTiled, true>)
-		       : plan.sv == 10 ? reinterpret_cast<const void *>(&demod_wave_kernel<10, 0, true>)
-				       : reinterpret_cast<const void *>(&demod_wave_kernel<4, 0, true>);
+	const void *fn = g.tiled ? reinterpret_cast<const void *>(&demod_wave_kernel<10, kTiled, true, false>)
+		       : plan.sv == 10 ? reinterpret_cast<const void *>(&demod_wave_kernel<10, 0, true, false>)
+				       : reinterpret_cast<const void *>(&demod_wave_kernel<4, 0, true, false>);
 	if ( hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes) != hipSuccess )
 	    return -5;
 	hipEvent_t fork = (hipEvent_t)ch.ev_fork;
@@ -1967,13 +1970,13 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
 		hipStream_t gs = (hipStream_t)ch.streams[gi];
 		au.d_state = ch.d_state + glo[gi];
 		if ( g.tiled )
-		    hipLaunchKernelGGL((demod_wave_kernel<10, kTiled, true>), dim3((unsigned)gio[gi].nstreams), dim3(64),
+		    hipLaunchKernelGGL((demod_wave_kernel<10, kTiled, true, false>), dim3((unsigned)gio[gi].nstreams), dim3(64),
 				       plan.lds_bytes, gs, d_cfg, d_tw, gio[gi], g, au);
 		else if ( plan.sv == 10 )
-		    hipLaunchKernelGGL((demod_wave_kernel<10, 0, true>), dim3((unsigned)gio[gi].nstreams), dim3(64),
+		    hipLaunchKernelGGL((demod_wave_kernel<10, 0, true, false>), dim3((unsigned)gio[gi].nstreams), dim3(64),
 				       plan.lds_bytes, gs, d_cfg, d_tw, gio[gi], g, au);
 		else
-		    hipLaunchKernelGGL((demod_wave_kernel<4, 0, true>), dim3((unsigned)gio[gi].nstreams), dim3(64),
+		    hipLaunchKernelGGL((demod_wave_kernel<4, 0, true, false>), dim3((unsigned)gio[gi].nstreams), dim3(64),
 				       plan.lds_bytes, gs, d_cfg, d_tw, gio[gi], g, au);
 	    }
 	}
@@ -2001,14 +2004,23 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
 	return hipGetLastError() == hipSuccess ? 0 : -5;
     }
 #undef MIFSK_WAVE_LAUNCH_ST
-#define MIFSK_WAVE_LAUNCH(SV_, NQ_)										\
+    // (RING addressing and --auto-carrier have their own instantiations: the plain ones carry
+    // neither that code nor the registers it keeps alive)
+#define MIFSK_WAVE_LAUNCH_RA(SV_, NQ_, RA_)									\
     do {													\
-	const void *fn = reinterpret_cast<const void *>(&demod_wave_kernel<SV_, NQ_>);				\
+	const void *fn = reinterpret_cast<const void *>(&demod_wave_kernel<SV_, NQ_, false, RA_>);		\
 	if ( hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes)		\
 		!= hipSuccess )											\
 	    return -5;												\
-	hipLaunchKernelGGL((demod_wave_kernel<SV_, NQ_>), dim3((unsigned)io.nstreams), dim3(64),		\
+	hipLaunchKernelGGL((demod_wave_kernel<SV_, NQ_, false, RA_>), dim3((unsigned)io.nstreams), dim3(64),	\
 				   plan.lds_bytes, st, d_cfg, d_tw, io, g, au);						\
+    } while (0)
+#define MIFSK_WAVE_LAUNCH(SV_, NQ_)										\
+    do {													\
+	if ( ha.ring_exact || ha.autodetect )									\
+	    MIFSK_WAVE_LAUNCH_RA(SV_, NQ_, true);								\
+	else													\
+	    MIFSK_WAVE_LAUNCH_RA(SV_, NQ_, false);								\
     } while (0)
     if ( g.tiled ) {
 	MIFSK_WAVE_LAUNCH(10, kTiled);				// RTTY and slower
@@ -2021,6 +2033,7 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
 	else                 MIFSK_WAVE_LAUNCH(4, 0);
     }
 #undef MIFSK_WAVE_LAUNCH
+#undef MIFSK_WAVE_LAUNCH_RA
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

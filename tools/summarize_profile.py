@@ -59,7 +59,9 @@ def code_object_figures(kernel):
             name = re.sub(r"\s+", "", m.group(1)) if m else ""
             # (the plan names the instantiation without a trailing ", false"; chained launches
             # run the resumable twin, named in full)
-            if m and want in (name, name.replace(",false>", ">")):
+            # (resource names carry every template argument: <SV, NQ, resumable, ring/auto-capable>)
+            short = name.replace(",false,false>", ">").replace(",true,false>", ",true>")
+            if m and want in (name, short, name.replace(",false>", ">")):
                 return {"vgpr": int(m.group(2)), "agpr": int(m.group(3)), "vgpr_spill": int(m.group(4)),
                         "sgpr": int(m.group(5)), "sgpr_spill": int(m.group(6)), "scratch_bytes": int(m.group(7)),
                         "source": os.path.relpath(path, ROOT)}
