@@ -345,6 +345,24 @@ def run_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, cp
     verdicts = [stream_ok(gpu_bytes[i], int(gpu_nbytes[i]), payloads[i], lo + i) for i in range(nstreams)]
     ok_streams = sum(1 for v in verdicts if v)
     judged = sum(1 for v in verdicts if v is not None)
+    # SURVEY 8(d), configs[4]: streams whose whole payload survives, per condition of the sweep
+    # (what the reference's algorithm loses to the noise -- the GPU's frames equal the oracle's
+    # either way, tests/test_gpu_fullsize.py -- and what byte error rate is left)
+    by_condition = None
+    if name == "same":
+        by_condition = {}
+        for k, (kind, v) in enumerate(SAME_CONDITIONS):
+            label = "clean" if v is None else ("%g dB SNR" % v if kind == "snr_db" else "DC offset %g" % v)
+            mine = [i for i in range(nstreams) if (lo + i) % 8 == k]
+            whole = sent = out = 0
+            for i in mine:
+                got = gpu_bytes[i][:int(gpu_nbytes[i])].tobytes()
+                pay = payloads[i].tobytes()
+                whole += pay in got
+                sent += len(pay)
+                out += len(got)
+            by_condition[label] = {"streams": len(mine), "whole_payload": whole,
+                                   "bytes_decoded_over_sent": out / max(1, sent)}
     # the bytes gathered from the peers are checked too (rank 0): each peer's streams are
     # regenerated from their global ids
     peers_ok = peers_judged = 0
@@ -395,6 +413,8 @@ def run_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, cp
             "payload_roundtrip_ok_streams": "%d/%d" % (ok_streams, judged),
             "device": ctx.device_name,
         }
+        if by_condition is not None:
+            line["payload_by_condition"] = by_condition
         if world > 1:
             line["payload_roundtrip_ok_streams_gathered_from_peers"] = "%d/%d" % (peers_ok, peers_judged)
         if world == 1 and cpu_leg:
@@ -560,6 +580,8 @@ def main():
                     "launch": rf["launch"],
                     "payload_roundtrip_ok_streams": sub["payload_roundtrip_ok_streams"],
                 }
+                if "payload_by_condition" in sub:
+                    extra[other]["payload_by_condition"] = sub["payload_by_condition"]
                 if "payload_roundtrip_ok_streams_gathered_from_peers" in sub:
                     extra[other]["payload_roundtrip_ok_streams_gathered_from_peers"] = \
                         sub["payload_roundtrip_ok_streams_gathered_from_peers"]
