@@ -165,13 +165,17 @@ __device__ __forceinline__ void wave_build_table( double *tw_own, const double *
 
 // everything the kernel keeps per stream beyond the loop's scalars
 // NQ: > 0 = the resident-table correlator for windows of 4 NQ samples (linear
-// LATTICE); 0 = any bit length; kTiled = the instantiation for long windows
-// read from global memory through the LDS tile (no linear LATTICE in it)
+// LATTICE); 0 = any bit length, linear LATTICE; kDirect = any bit length, the lattice's
+// windows streamed per lane from global memory (or no lattice): no staging rounds, no round
+// prefetch registers; kTiled = the instantiation for long windows read from global memory
+// through the LDS tile (no linear LATTICE in it either)
 constexpr int kTiled = -1;
+constexpr int kDirect = -2;
 
 template <int SV, int NQ>
 struct Wave {
     static constexpr uint32_t kRoundFloats = 64u * SV * 4u;	// samples one staging round loads
+    static constexpr bool kLinear = NQ >= 0;			// the lattice of this instantiation is the linear one
     const DevCfg	&cfg;
     const WaveGeom	&g;
     const double	*tw;
@@ -223,9 +227,11 @@ struct Wave {
 	  k0_valid(false), pref_lo(0xFFFFFFFFu),cnt(counters), cnt_on(counting), cyc_block(0), cyc_scan(0), cyc_stage(0), cyc_corr(0), cyc_conf(0),
 	  cyc_s_stage(0), cyc_s_corr(0), cyc_s_conf(0)
     {
+	if constexpr ( kLinear ) {
 #pragma unroll
-	for ( int i = 0; i < SV; i++ )
-	    pbuf[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	    for ( int i = 0; i < SV; i++ )
+		pbuf[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	}
 	load_resident_twiddles();
     }
 
@@ -249,10 +255,12 @@ struct Wave {
     // nothing prefetched is wanted any more: end the registers' live ranges
     __device__ __forceinline__ void drop_prefetch()
     {
-	pref_lo = 0xFFFFFFFFu;
+	if constexpr ( kLinear ) {
+	    pref_lo = 0xFFFFFFFFu;
 #pragma unroll
-	for ( int i = 0; i < SV; i++ )
-	    pbuf[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	    for ( int i = 0; i < SV; i++ )
+		pbuf[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	}
     }
 
     // index of the scored lattice frame whose first try is at p, or ~0u
@@ -397,7 +405,7 @@ struct Wave {
 	const uint32_t t0 = MIFSK_WCLOCK();
 	const uint32_t nb = cfg.n_bits;
 	const uint32_t W = cfg.lat_grid ? F * ( nb - 1u ) + 1u : F * nb;
-	if ( NQ != kTiled && g.lat_mode == LAT_LINEAR ) {
+	if constexpr ( kLinear ) {
 	    const uint32_t rw = g.round_wins;
 	    for ( uint32_t w0 = 0; w0 < W; w0 += rw ) {
 		const uint32_t nw = W - w0 < rw ? W - w0 : rw;
@@ -1020,7 +1028,7 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
     uint32_t safe_limit = rows_after == 0 ? N
 			: rows_after > 0xFFFF0000ull ? 0xFFFF0000u : (uint32_t)rows_after;
     bool lattice_ok = g.lat_mode != LAT_NONE;
-    if ( g.lat_mode == LAT_LINEAR && safe_limit < Wave<SV, NQ>::kRoundFloats ) {
+    if ( Wave<SV, NQ>::kLinear && safe_limit < Wave<SV, NQ>::kRoundFloats ) {
 	lattice_ok = false;
 	safe_limit = Wave<SV, NQ>::kRoundFloats;
     }
@@ -1897,13 +1905,16 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
     // lengths that have one (linear LATTICE only)
     const uint32_t nq = ( g.lat_mode == LAT_LINEAR && cfg.bit_nsamples % 4u == 0u ) ? cfg.bit_nsamples / 4u : 0u;
     if ( plan_only ) {
+	const bool lin = g.lat_mode == LAT_LINEAR;	// (generic instantiations: <., 0> linear lattice, <., -2> direct or none)
 	plan_only->kernel = chain_g ? ( g.tiled ? "mifsk::demod_wave_kernel<10, -1, true>"
-					 : plan.sv == 10 ? "mifsk::demod_wave_kernel<10, 0, true>"
-							 : "mifsk::demod_wave_kernel<4, 0, true>" )
+					 : plan.sv == 10 ? ( lin ? "mifsk::demod_wave_kernel<10, 0, true>" : "mifsk::demod_wave_kernel<10, -2, true>" )
+							 : ( lin ? "mifsk::demod_wave_kernel<4, 0, true>" : "mifsk::demod_wave_kernel<4, -2, true>" ) )
 			  : g.tiled ? "mifsk::demod_wave_kernel<10, -1>"
 			  : plan.sv == 10 ? ( nq == 10u ? "mifsk::demod_wave_kernel<10, 10>"
-					   : nq == 5u ? "mifsk::demod_wave_kernel<10, 5>" : "mifsk::demod_wave_kernel<10, 0>" )
-					  : ( nq == 1u ? "mifsk::demod_wave_kernel<4, 1>" : "mifsk::demod_wave_kernel<4, 0>" );
+					   : nq == 5u ? "mifsk::demod_wave_kernel<10, 5>"
+					   : lin ? "mifsk::demod_wave_kernel<10, 0>" : "mifsk::demod_wave_kernel<10, -2>" )
+					  : ( nq == 1u ? "mifsk::demod_wave_kernel<4, 1>"
+					      : lin ? "mifsk::demod_wave_kernel<4, 0>" : "mifsk::demod_wave_kernel<4, -2>" );
 	plan_only->workgroup_size = 64;
 	plan_only->lds_bytes = (uint32_t)plan.lds_bytes;
 	plan_only->lattice_mode = g.lat_mode;
@@ -1918,9 +1929,12 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
 	const WaveChain &ch = *ha.chain;
 	if ( (size_t)io.nstreams > ch.state_cap )
 	    return -12;
+	const bool lin = g.lat_mode == LAT_LINEAR;
 	const void *fn = g.tiled ? reinterpret_cast<const void *>(&demod_wave_kernel<10, kTiled, true, false>)
-		       : plan.sv == 10 ? reinterpret_cast<const void *>(&demod_wave_kernel<10, 0, true, false>)
-				       : reinterpret_cast<const void *>(&demod_wave_kernel<4, 0, true, false>);
+		       : plan.sv == 10 ? ( lin ? reinterpret_cast<const void *>(&demod_wave_kernel<10, 0, true, false>)
+					       : reinterpret_cast<const void *>(&demod_wave_kernel<10, kDirect, true, false>) )
+				       : ( lin ? reinterpret_cast<const void *>(&demod_wave_kernel<4, 0, true, false>)
+					       : reinterpret_cast<const void *>(&demod_wave_kernel<4, kDirect, true, false>) );
 	if ( hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes) != hipSuccess )
 	    return -5;
 	hipEvent_t fork = (hipEvent_t)ch.ev_fork;
@@ -1972,11 +1986,17 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
 		if ( g.tiled )
 		    hipLaunchKernelGGL((demod_wave_kernel<10, kTiled, true, false>), dim3((unsigned)gio[gi].nstreams), dim3(64),
 				       plan.lds_bytes, gs, d_cfg, d_tw, gio[gi], g, au);
-		else if ( plan.sv == 10 )
+		else if ( plan.sv == 10 && lin )
 		    hipLaunchKernelGGL((demod_wave_kernel<10, 0, true, false>), dim3((unsigned)gio[gi].nstreams), dim3(64),
 				       plan.lds_bytes, gs, d_cfg, d_tw, gio[gi], g, au);
-		else
+		else if ( plan.sv == 10 )
+		    hipLaunchKernelGGL((demod_wave_kernel<10, kDirect, true, false>), dim3((unsigned)gio[gi].nstreams), dim3(64),
+				       plan.lds_bytes, gs, d_cfg, d_tw, gio[gi], g, au);
+		else if ( lin )
 		    hipLaunchKernelGGL((demod_wave_kernel<4, 0, true, false>), dim3((unsigned)gio[gi].nstreams), dim3(64),
+				       plan.lds_bytes, gs, d_cfg, d_tw, gio[gi], g, au);
+		else
+		    hipLaunchKernelGGL((demod_wave_kernel<4, kDirect, true, false>), dim3((unsigned)gio[gi].nstreams), dim3(64),
 				       plan.lds_bytes, gs, d_cfg, d_tw, gio[gi], g, au);
 	    }
 	}
@@ -1998,9 +2018,12 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
     } while (0)
     if ( ha.d_state ) {
 	// mifsk_demod_slab: the instantiations with the state code, generic correlators
-	if ( g.tiled )          MIFSK_WAVE_LAUNCH_ST(10, kTiled);
-	else if ( plan.sv == 10 ) MIFSK_WAVE_LAUNCH_ST(10, 0);
-	else                    MIFSK_WAVE_LAUNCH_ST(4, 0);
+	const bool lin = g.lat_mode == LAT_LINEAR;
+	if ( g.tiled )                 MIFSK_WAVE_LAUNCH_ST(10, kTiled);
+	else if ( plan.sv == 10 && lin ) MIFSK_WAVE_LAUNCH_ST(10, 0);
+	else if ( plan.sv == 10 )      MIFSK_WAVE_LAUNCH_ST(10, kDirect);
+	else if ( lin )                MIFSK_WAVE_LAUNCH_ST(4, 0);
+	else                           MIFSK_WAVE_LAUNCH_ST(4, kDirect);
 	return hipGetLastError() == hipSuccess ? 0 : -5;
     }
 #undef MIFSK_WAVE_LAUNCH_ST
@@ -2027,10 +2050,12 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
     } else if ( plan.sv == 10 ) {
 	if ( nq == 10u )     MIFSK_WAVE_LAUNCH(10, 10);		// 1200 baud at 48 kHz
 	else if ( nq == 5u ) MIFSK_WAVE_LAUNCH(10, 5);		// 2400 baud; 1200 baud at 24 kHz
-	else                 MIFSK_WAVE_LAUNCH(10, 0);
+	else if ( g.lat_mode == LAT_LINEAR ) MIFSK_WAVE_LAUNCH(10, 0);
+	else                 MIFSK_WAVE_LAUNCH(10, kDirect);
     } else {
 	if ( nq == 1u )      MIFSK_WAVE_LAUNCH(4, 1);		// 12000 baud
-	else                 MIFSK_WAVE_LAUNCH(4, 0);
+	else if ( g.lat_mode == LAT_LINEAR ) MIFSK_WAVE_LAUNCH(4, 0);
+	else                 MIFSK_WAVE_LAUNCH(4, kDirect);	// SAME
     }
 #undef MIFSK_WAVE_LAUNCH
 #undef MIFSK_WAVE_LAUNCH_RA

@@ -1,6 +1,4 @@
 set -u
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r3q; mkdir -p $O
-( time timeout 600 python bench.py --no-cpu --no-h2d --no-extra --config same --steps 5 > $O/same.json 2>$O/same.err ) 2>&1 | grep real
-python -c "
-import json; l=json.loads(open('$O/same.json').read().strip().splitlines()[-1]); print(l['roofline']['kernel_ms_avg'], l['payload_roundtrip_ok_streams']); print(json.dumps(l['payload_by_condition'], indent=1))"
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_chain.py tests/test_gpu_slabs.py tests/test_gpu_fullsize.py -q --timeout 900 -x 2>&1 | tail -3
+for c in same 12000 rtty; do bash tools/gpu/ab.sh $c minimodem_amd/libmifsk_base.so minimodem_amd/libmifsk.so 2; done
