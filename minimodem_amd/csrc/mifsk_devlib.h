@@ -435,12 +435,46 @@ __device__ __forceinline__ float wave_shr1( float v )
 // lower neighbour's result, i.e. the state BEFORE each lane's frame -- inside the
 // asm as well: around a DPP intrinsic the compiler narrows EXEC to the lanes whose
 // result is used, and a lane whose SOURCE lane is masked off is not written.
+// totals == false: the running sums of confidence and amplitude (xsc, xsa: what a NOCARRIER
+// line reports, minimodem.c:271-275) are not wanted -- no episode records, no saved state --
+// and their two instructions per step are left out; xsc / xsa / bsc / bsa are then untouched.
 __device__ __forceinline__ void replay_scan_asm( float &xt, float &xpk, float &xsc, float &xsa,
-	float &bt, float &bpk, float &bsc, float &bsa, float cv, float av, uint32_t K )
+	float &bt, float &bpk, float &bsc, float &bsa, float cv, float av, uint32_t K, bool totals = true )
 {
     float yt = xt, ypk = xpk, ysc = xsc, ysa = xsa;
     float tmp = xt + xt;
     const uint32_t pairs = K / 2u;		// 2 * pairs >= K - 1 steps
+    if ( !totals ) {
+#define MIFSK_SCAN_STEP_LEAN(ST, SPK, DT, DPK)								\
+	"v_add_f32_dpp %[tmp], " ST ", %[av] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"		\
+	"v_max_f32_dpp " DPK ", " SPK ", %[cv] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"		\
+	"s_nop 0\n\t"											\
+	"v_mul_f32_e32 " DT ", 0.5, %[tmp]\n\t"								\
+	"s_nop 1\n\t"
+	// (DT and DPK are read through DPP by the next step: two wait states after each write)
+	uint32_t n = pairs;
+	asm volatile(
+	    "s_nop 1\n\t"
+	    "s_cmp_eq_u32 %[n], 0\n\t"
+	    "s_cbranch_scc1 2f\n\t"
+	    "1:\n\t"
+	    MIFSK_SCAN_STEP_LEAN("%[xt]", "%[xpk]", "%[yt]", "%[ypk]")
+	    "s_sub_u32 %[n], %[n], 1\n\t"
+	    MIFSK_SCAN_STEP_LEAN("%[yt]", "%[ypk]", "%[xt]", "%[xpk]")
+	    "s_cmp_lg_u32 %[n], 0\n\t"
+	    "s_cbranch_scc1 1b\n\t"
+	    "s_nop 1\n\t"
+	    "2:\n\t"
+	    "v_mov_b32_dpp %[bt], %[xt] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+	    "v_mov_b32_dpp %[bpk], %[xpk] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+	    "s_nop 1\n\t"
+	    : [bt] "+v"(bt), [bpk] "+v"(bpk), [xt] "+v"(xt), [xpk] "+v"(xpk),
+	      [yt] "+v"(yt), [ypk] "+v"(ypk), [tmp] "+v"(tmp), [n] "+s"(n)
+	    : [cv] "v"(cv), [av] "v"(av)
+	    : "scc");
+#undef MIFSK_SCAN_STEP_LEAN
+	return;
+    }
 #define MIFSK_SCAN_STEP(ST, SPK, SSC, SSA, DT, DPK, DSC, DSA)						\
 	"v_add_f32_dpp %[tmp], " ST ", %[av] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"		\
 	"v_mul_f32_e32 " DT ", 0.5, %[tmp]\n\t"	/* >= 2 instructions before DT is read by DPP */	\
@@ -487,7 +521,8 @@ __device__ __forceinline__ void replay_scan_asm( float &xt, float &xpk, float &x
 // Lane 0 keeps its seed as there: the DPP instructions never write it, its
 // threshold stays -inf (so the comparison is false) and its `mx` stays the seed.
 __device__ __forceinline__ void replay_scan_soft( float &xt, float &xpk, float &xsc, float &xsa,
-	float &bt, float &bpk, float &bsc, float &bsa, float cv, float av, uint32_t K, uint32_t lane )
+	float &bt, float &bpk, float &bsc, float &bsa, float cv, float av, uint32_t K, uint32_t lane,
+	bool totals = true )
 {
     (void)lane;
     float yt = xt, ypk = xpk, ysc = xsc, ysa = xsa;
@@ -495,6 +530,41 @@ __device__ __forceinline__ void replay_scan_soft( float &xt, float &xpk, float &
     float thr = -INFINITY, mx = xpk;
     const float k075 = 0.75f;
     const uint32_t pairs = K / 2u;		// 2 * pairs >= K - 1 steps
+    if ( !totals ) {
+	// (replay_scan_asm: without the two running sums; the step's other six instructions and
+	// their spacing are those of the full step below)
+#define MIFSK_SOFT_STEP_LEAN(ST, SPK, DT, DPK)								\
+	"v_add_f32_dpp %[tmp], " ST ", %[av] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"		\
+	"v_mul_f32_dpp %[thr], " SPK ", %[k075] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"		\
+	"v_max_f32_dpp %[mx], " SPK ", %[cv] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"		\
+	"v_mul_f32_e32 " DT ", 0.5, %[tmp]\n\t"								\
+	"v_cmp_lt_f32_e32 vcc, %[cv], %[thr]\n\t"								\
+	"v_cndmask_b32_e32 " DPK ", %[mx], %[cv], vcc\n\t"
+	uint32_t n = pairs;
+	asm volatile(
+	    "s_nop 1\n\t"
+	    "s_cmp_eq_u32 %[n], 0\n\t"
+	    "s_cbranch_scc1 2f\n\t"
+	    "1:\n\t"
+	    MIFSK_SOFT_STEP_LEAN("%[xt]", "%[xpk]", "%[yt]", "%[ypk]")
+	    "s_sub_u32 %[n], %[n], 1\n\t"
+	    "s_nop 0\n\t"
+	    MIFSK_SOFT_STEP_LEAN("%[yt]", "%[ypk]", "%[xt]", "%[xpk]")
+	    "s_cmp_lg_u32 %[n], 0\n\t"
+	    "s_nop 0\n\t"
+	    "s_cbranch_scc1 1b\n\t"
+	    "s_nop 1\n\t"
+	    "2:\n\t"
+	    "v_mov_b32_dpp %[bt], %[xt] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+	    "v_mov_b32_dpp %[bpk], %[xpk] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+	    "s_nop 1\n\t"
+	    : [bt] "+v"(bt), [bpk] "+v"(bpk), [xt] "+v"(xt), [xpk] "+v"(xpk),
+	      [yt] "+v"(yt), [ypk] "+v"(ypk), [tmp] "+v"(tmp), [thr] "+v"(thr), [mx] "+v"(mx), [n] "+s"(n)
+	    : [cv] "v"(cv), [av] "v"(av), [k075] "v"(k075)
+	    : "scc", "vcc");
+#undef MIFSK_SOFT_STEP_LEAN
+	return;
+    }
 #define MIFSK_SOFT_STEP(ST, SPK, SSC, SSA, DT, DPK, DSC, DSA)						\
 	"v_add_f32_dpp %[tmp], " ST ", %[av] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"		\
 	"v_mul_f32_dpp %[thr], " SPK ", %[k075] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"		\

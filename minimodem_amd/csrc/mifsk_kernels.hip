@@ -807,7 +807,7 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 		// lane 0 keeps what these are seeded with, the current state
 		float my_t = track_amplitude, my_pk = peak_confidence;
 		float my_sc = confidence_total, my_sa = amplitude_total;
-		replay_scan_asm(xt, xpk, xsc, xsa, my_t, my_pk, my_sc, my_sa, cv, av, K);
+		replay_scan_asm(xt, xpk, xsc, xsa, my_t, my_pk, my_sc, my_sa, cv, av, K, o.eps != nullptr);
 		cyc_dpp += MIFSK_CLOCK() - t_dpp;
 		const float t = xt, pk = xpk, sc = xsc, sa = xsa;	// state after frame `lane`
 		const bool ok = have

@@ -1158,6 +1158,11 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 
     const ZigZag zc0(cfg, 0u), zc1(cfg, 1u), zf0(cfg, 2u), zf1(cfg, 3u);
     const uint32_t la = cfg.lock_advance;
+    // the episodes' running totals of confidence and amplitude are reported in episode records
+    // and carried in the saved state: nowhere else (the lattice replay skips them otherwise)
+    // (a chained launch saves state too, but only for its own next chunk, which wants what this
+    // one wants)
+    const bool want_totals = o.eps != nullptr || ( ST && au.append == 0u );
 
     // every pass through the loop moves the cursor forward (or ends the loop):
     // a bound far above anything reachable turns a logic error into a flagged
@@ -1231,9 +1236,9 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 		float my_t = track_amplitude, my_pk = peak_confidence;
 		float my_sc = confidence_total, my_sa = amplitude_total;
 		if ( soft )
-		    replay_scan_soft(xt, xpk, xsc, xsa, my_t, my_pk, my_sc, my_sa, cv, av, K, lane);
+		    replay_scan_soft(xt, xpk, xsc, xsa, my_t, my_pk, my_sc, my_sa, cv, av, K, lane, want_totals);
 		else
-		    replay_scan_asm(xt, xpk, xsc, xsa, my_t, my_pk, my_sc, my_sa, cv, av, K);
+		    replay_scan_asm(xt, xpk, xsc, xsa, my_t, my_pk, my_sc, my_sa, cv, av, K, want_totals);
 		const bool ok = have
 		    && cv > 0.0f && cv >= cfg.search_limit	// fsk.c:492,499: first try ends the scan
 		    && ( soft || !( cv < my_pk * 0.75f ) )	// minimodem.c:1278

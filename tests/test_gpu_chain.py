@@ -93,6 +93,32 @@ def test_chained_equals_single_launch_on_noisy_ragged_batch(gpu, monkeypatch, mo
         assert_stream_equal(res, i, O.oracle_rx_stream(ocfg, streams[i]), mode)
 
 
+def test_chained_without_episode_records(gpu, monkeypatch):
+    """... and with no episode records asked for (the replay then leaves the running totals out,
+    in every chunk): frames and bytes are the single launch's."""
+    M, torch, ctx = gpu
+    cfg = M.rx_config("same")
+    ocfg = O.oracle_config("same")
+    rng = np.random.default_rng(5)
+    streams = []
+    for i in range(8):
+        words = rng.integers(32, 127, size=int(rng.integers(30, 80))).astype(np.uint8)
+        x = M.synthesize(cfg, np.concatenate([np.full(16, 0xAB, np.uint8), words]), amplitude=0.6)
+        x = x + rng.normal(0, [0.0, 0.03, 0.1, 0.2][i % 4], len(x)).astype(np.float32)
+        streams.append(x.astype(np.float32))
+    monkeypatch.setenv("MIFSK_EXPERIMENT", "1")
+    monkeypatch.setenv("MIFSK_CHAIN", "2,5")
+    stride = (max(len(s) for s in streams) + 3) & ~3
+    assert _chained(M, ctx, cfg, len(streams), stride) == (2, 5)
+    res = run_gpu_streams(M, torch, ctx, cfg, streams, want=("bytes", "frames"), engine="wave")
+    for i, s in enumerate(streams):
+        ref = O.oracle_rx_stream(ocfg, s)
+        nf = int(res["nframes"][i])
+        assert nf == len(ref["frames"])
+        assert res["frames"][i, :nf].tobytes() == ref["frames"].tobytes(), i
+        assert res["bytes"][i, :int(res["nbytes"][i])].tobytes() == ref["bytes"]
+
+
 def test_which_batches_are_cut(gpu):
     """The library's own rule: flat wavefront-engine batches of more streams than the chip holds
     at once, streams long enough to cut, an instantiation with a resumable twin."""

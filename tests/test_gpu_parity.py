@@ -113,6 +113,36 @@ def test_demod_matches_oracle_and_reference_on_goldens(gpu, name, variant):
     assert [l for l in elines if l.startswith("### NOCARRIER")] == g["nocarrier"]
 
 
+@pytest.mark.parametrize("variant", [("wave", False), ("workgroup", False)], ids=["wave-flat", "workgroup-flat"])
+@pytest.mark.parametrize("name", G.names())
+def test_frames_equal_oracle_when_no_episode_records_are_asked_for(gpu, name, variant):
+    """Without episode records (and without saved state) the lattice replay leaves the episodes'
+    running totals out (replay_scan_asm / _soft, totals == false): the frames -- bits, starts,
+    flags, confidence and amplitude bit patterns -- and the bytes must not notice."""
+    M, torch, ctx = gpu
+    engine, ring = variant
+    g = G.load(name)
+    cfg = M.rx_config(**g["cfg_kwargs"])
+    if engine == "workgroup" and cfg.auto_carrier_threshold > 0:
+        pytest.skip("--auto-carrier runs on the wavefront engine only")
+    ocfg = O.oracle_config(**g["cfg_kwargs"])
+    x = g["samples"]
+    streams = [x, x[:int(len(x) * 0.7)]] if len(x) < 2_000_000 else [x]
+    res = run_gpu_streams(M, torch, ctx, cfg, streams, want=("bytes", "frames", "bits"), engine=engine, ring=ring)
+    for i, s in enumerate(streams):
+        ref = O.oracle_rx_stream(ocfg, s)
+        nf = int(res["nframes"][i])
+        assert nf == len(ref["frames"]), (name, i)
+        got = res["frames"][i, :nf]
+        for field in ("bits", "start", "flags"):
+            assert np.array_equal(got[field], ref["frames"][field]), (name, i, field)
+        for field in ("confidence", "amplitude"):
+            assert _bits_equal_f32(got[field], ref["frames"][field]), (name, i, field)
+        assert res["bytes"][i, :int(res["nbytes"][i])].tobytes() == ref["bytes"]
+        assert np.array_equal(res["bits"][i, :nf], ref["frames"]["bits"])
+        assert int(res["status"][i]) == 0
+
+
 @pytest.mark.parametrize("name", G.names())
 def test_find_frame_batch_matches_reference_trace(gpu, name):
     M, torch, ctx = gpu
