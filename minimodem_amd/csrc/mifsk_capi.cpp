@@ -676,8 +676,7 @@ static int demod_batch_wave( mifsk_ctx *ctx, const mifsk_rx_config *cfg, const D
     ha.final = final;
     // a whole-stream call over a plain batch may be cut into chained launches (the launcher
     // decides by the batch's shape)
-    ha.chain_ok = !d_state && !( io->flags & MIFSK_IO_RING_EXACT ) && !( cfg->auto_carrier_threshold > 0.0f )
-	       && !io->d_counters;
+    ha.chain_ok = !d_state && !( io->flags & MIFSK_IO_RING_EXACT ) && !io->d_counters;
     // (--auto-carrier retunes per stream: its rotation factors come from the stream's own table)
     if ( tables && !( cfg->auto_carrier_threshold > 0.0f ) )
 	for ( int k = 0; k < 5; k++ ) {
@@ -737,7 +736,10 @@ static int demod_batch_wave( mifsk_ctx *ctx, const mifsk_rx_config *cfg, const D
 	    if ( rc )
 		return rc;
 	    ha.chain = &ctx->chain;
-	    return mifsk::launch_demod_wave(d, d_cfg, d_tw, *io, ha, stream);
+	    rc = mifsk::launch_demod_wave(d, d_cfg, d_tw, *io, ha, stream);
+	    // (the caller's stream has joined the groups' by now: freed in stream order behind them)
+	    if ( scratch_tw ) (void)hipFreeAsync(scratch_tw, st);
+	    return rc;
 	}
     }
     rc = mifsk::launch_demod_wave(d, d_cfg, d_tw, *io, ha, stream);

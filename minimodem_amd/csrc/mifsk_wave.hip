@@ -1832,7 +1832,7 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
 	const uint32_t by_regs = ( plan.g.tiled || plan.sv == 10 ? 2u : 4u ) * 4u;
 	const uint64_t slots = (uint64_t)( by_lds < by_regs ? by_lds : by_regs ) * (uint64_t)ncu;
 	const bool allowed = ( plan_only ? ha.chain_ok : ha.chain != nullptr ) && st_kernel && !ha.d_state
-			  && !ha.ring_exact && !ha.autodetect && !io.d_counters && io.nstreams > 0;
+			  && !ha.ring_exact && !io.d_counters && io.nstreams > 0;
 	if ( allowed && (uint64_t)io.nstreams > slots && ha.samplebuf_size > 0u ) {
 	    chain_g = 2u;
 	    chain_k = io.nsamples / ( 8u * ha.samplebuf_size );
@@ -1935,11 +1935,15 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
 	if ( (size_t)io.nstreams > ch.state_cap )
 	    return -12;
 	const bool lin = g.lat_mode == LAT_LINEAR;
-	const void *fn = g.tiled ? reinterpret_cast<const void *>(&demod_wave_kernel<10, kTiled, true, false>)
-		       : plan.sv == 10 ? ( lin ? reinterpret_cast<const void *>(&demod_wave_kernel<10, 0, true, false>)
-					       : reinterpret_cast<const void *>(&demod_wave_kernel<10, kDirect, true, false>) )
-				       : ( lin ? reinterpret_cast<const void *>(&demod_wave_kernel<4, 0, true, false>)
-					       : reinterpret_cast<const void *>(&demod_wave_kernel<4, kDirect, true, false>) );
+	// which resumable instantiation: staging width x lattice kind x (--auto-carrier or not)
+#define MIFSK_CHAIN_PICK(RA_)											\
+	( g.tiled ? reinterpret_cast<const void *>(&demod_wave_kernel<10, kTiled, true, RA_>)			\
+	  : plan.sv == 10 ? ( lin ? reinterpret_cast<const void *>(&demod_wave_kernel<10, 0, true, RA_>)		\
+				  : reinterpret_cast<const void *>(&demod_wave_kernel<10, kDirect, true, RA_>) )	\
+			  : ( lin ? reinterpret_cast<const void *>(&demod_wave_kernel<4, 0, true, RA_>)		\
+				  : reinterpret_cast<const void *>(&demod_wave_kernel<4, kDirect, true, RA_>) ) )
+	const void *fn = ha.autodetect ? MIFSK_CHAIN_PICK(true) : MIFSK_CHAIN_PICK(false);
+#undef MIFSK_CHAIN_PICK
 	if ( hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes) != hipSuccess )
 	    return -5;
 	hipEvent_t fork = (hipEvent_t)ch.ev_fork;
@@ -1988,21 +1992,10 @@ int launch_demod_wave( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_t
 		    continue;
 		hipStream_t gs = (hipStream_t)ch.streams[gi];
 		au.d_state = ch.d_state + glo[gi];
-		if ( g.tiled )
-		    hipLaunchKernelGGL((demod_wave_kernel<10, kTiled, true, false>), dim3((unsigned)gio[gi].nstreams), dim3(64),
-				       plan.lds_bytes, gs, d_cfg, d_tw, gio[gi], g, au);
-		else if ( plan.sv == 10 && lin )
-		    hipLaunchKernelGGL((demod_wave_kernel<10, 0, true, false>), dim3((unsigned)gio[gi].nstreams), dim3(64),
-				       plan.lds_bytes, gs, d_cfg, d_tw, gio[gi], g, au);
-		else if ( plan.sv == 10 )
-		    hipLaunchKernelGGL((demod_wave_kernel<10, kDirect, true, false>), dim3((unsigned)gio[gi].nstreams), dim3(64),
-				       plan.lds_bytes, gs, d_cfg, d_tw, gio[gi], g, au);
-		else if ( lin )
-		    hipLaunchKernelGGL((demod_wave_kernel<4, 0, true, false>), dim3((unsigned)gio[gi].nstreams), dim3(64),
-				       plan.lds_bytes, gs, d_cfg, d_tw, gio[gi], g, au);
-		else
-		    hipLaunchKernelGGL((demod_wave_kernel<4, kDirect, true, false>), dim3((unsigned)gio[gi].nstreams), dim3(64),
-				       plan.lds_bytes, gs, d_cfg, d_tw, gio[gi], g, au);
+		if ( ha.d_tw_scratch )		// (--auto-carrier: the group's streams' own tables)
+		    au.d_tw_scratch = ha.d_tw_scratch + (size_t)glo[gi] * g.tw_entries * 4u;
+		void *kargs[] = { (void *)&d_cfg, (void *)&d_tw, (void *)&gio[gi], (void *)&g, (void *)&au };
+		(void)hipLaunchKernel(fn, dim3((unsigned)gio[gi].nstreams), dim3(64), kargs, plan.lds_bytes, gs);
 	    }
 	}
 	const bool launched = hipGetLastError() == hipSuccess;

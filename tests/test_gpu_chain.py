@@ -36,8 +36,6 @@ def test_chained_launches_give_the_oracles_streams_on_goldens(gpu, monkeypatch, 
     M, torch, ctx = gpu
     g = G.load(name)
     cfg = M.rx_config(**g["cfg_kwargs"])
-    if cfg.auto_carrier_threshold > 0:
-        pytest.skip("--auto-carrier batches are not cut")
     x = g["samples"]
     if len(x) > 2_000_000:
         pytest.skip("one long stream: covered by the slab tests")
