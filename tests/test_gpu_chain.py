@@ -117,6 +117,49 @@ def test_chained_without_episode_records(gpu, monkeypatch):
         assert res["bytes"][i, :int(res["nbytes"][i])].tobytes() == ref["bytes"]
 
 
+def test_chained_edge_cases_equal_single_launch(gpu, monkeypatch):
+    """Empty rows, rows shorter than a chunk, fewer streams than groups, and output arrays too
+    small for the frames (the truncation flag and the counts must be the single launch's)."""
+    M, torch, ctx = gpu
+    cfg = M.rx_config("300")
+    rng = np.random.default_rng(11)
+    full = M.synthesize(cfg, rng.integers(32, 127, size=60).astype(np.uint8), amplitude=0.8)
+    streams = [full, np.zeros(0, np.float32), full[:900], full[:len(full) // 3], np.zeros(5000, np.float32), full]
+    monkeypatch.setenv("MIFSK_EXPERIMENT", "1")
+
+    def run(cut, which, frames_cap=None):
+        monkeypatch.setenv("MIFSK_CHAIN", cut)
+        sel = [streams[i] for i in which]
+        n = len(sel)
+        stride = (max([len(s) for s in sel] + [4]) + 3) & ~3
+        host = np.zeros((n, stride), np.float32)
+        lens = np.zeros(n, np.int32)
+        for i, x in enumerate(sel):
+            host[i, :len(x)] = x
+            lens[i] = len(x)
+        out = M.demod_batch(ctx, cfg, torch.from_numpy(host).cuda(), nsamples=torch.from_numpy(lens).cuda(),
+                            want=("bytes", "frames", "episodes", "bits"), episodes_cap=16, frames_cap=frames_cap,
+                            force_engine=True)
+        torch.cuda.synchronize()
+        return M.results_to_host(out)
+
+    for which, cap in ((range(6), None), (range(6), 7), ([0], None), ([0, 2], 3)):
+        which = list(which)
+        single = run("0,0", which, cap)
+        for cut in ("2,4", "3,9", "1,2"):
+            res = run(cut, which, cap)
+            for key in ("nframes", "nbytes", "nepisodes", "status"):
+                assert np.array_equal(res[key], single[key]), (which, cap, cut, key)
+            for i in range(len(which)):
+                nf = min(int(single["nframes"][i]), single["frames"].shape[1])
+                nb = min(int(single["nbytes"][i]), single["bytes"].shape[1])
+                ne = min(int(single["nepisodes"][i]), single["episodes"].shape[1])
+                assert res["frames"][i, :nf].tobytes() == single["frames"][i, :nf].tobytes(), (which, cap, cut, i)
+                assert res["bytes"][i, :nb].tobytes() == single["bytes"][i, :nb].tobytes()
+                assert res["episodes"][i, :ne].tobytes() == single["episodes"][i, :ne].tobytes()
+    assert int(run("2,4", list(range(6)), 7)["status"][0]) != 0		# (the full stream does not fit 7 frames)
+
+
 def test_which_batches_are_cut(gpu):
     """The library's own rule: flat wavefront-engine batches of more streams than the chip holds
     at once, streams long enough to cut, an instantiation with a resumable twin."""
