@@ -276,6 +276,10 @@ typedef struct mifsk_demod_io {
 #define MIFSK_CNT_CYC_CONFIDENCE 11
 #define MIFSK_CNT_CYC_BULK	12
 
+/* Asynchronous on `stream`: the outputs are complete when `stream` reaches the point
+ * behind the call.  (A large wavefront-engine batch is run as several launches on
+ * streams of the context's own, forked from and joined back into `stream` with events --
+ * mifsk_launch_info.chain_groups below; nothing changes for the caller.) */
 int mifsk_demod_batch( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
 	const mifsk_demod_io *io, void *stream );
 

@@ -401,7 +401,7 @@ extern "C" void mifsk_ctx_destroy( mifsk_ctx *ctx )
     }
     if ( ctx->host )
 	mifsk::host_work_destroy(ctx->host);
-    if ( ctx->chain_made ) {
+    {
 	for ( void *st : ctx->chain.streams )
 	    if ( st ) {
 		(void)hipStreamSynchronize((hipStream_t)st);
@@ -624,18 +624,24 @@ static int chain_prepare( mifsk_ctx *ctx, size_t ns )
 {
     mifsk::WaveChain &ch = ctx->chain;
     if ( !ctx->chain_made ) {
-	for ( void *&st : ch.streams ) {
-	    hipStream_t h = nullptr;
-	    HIP_OK(hipStreamCreateWithFlags(&h, hipStreamNonBlocking));
-	    st = h;
-	}
-	hipEvent_t e = nullptr;
-	HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-	ch.ev_fork = e;
-	for ( void *&d : ch.ev_done ) {
+	// (whatever an earlier, failed attempt made is kept and used: nothing is created twice)
+	for ( void *&st : ch.streams )
+	    if ( !st ) {
+		hipStream_t h = nullptr;
+		HIP_OK(hipStreamCreateWithFlags(&h, hipStreamNonBlocking));
+		st = h;
+	    }
+	if ( !ch.ev_fork ) {
+	    hipEvent_t e = nullptr;
 	    HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-	    d = e;
+	    ch.ev_fork = e;
 	}
+	for ( void *&d : ch.ev_done )
+	    if ( !d ) {
+		hipEvent_t e = nullptr;
+		HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+		d = e;
+	    }
 	ctx->chain_made = true;
     }
     if ( ns > ch.state_cap ) {
