@@ -150,6 +150,10 @@ int  mifsk_ctx_create( mifsk_ctx **ctx_out, int device );
 void mifsk_ctx_destroy( mifsk_ctx *ctx );
 const char *mifsk_ctx_device_name( const mifsk_ctx *ctx );
 int  mifsk_abi_version( void );
+/* sizeof() of the public struct `name` ("mifsk_demod_io", ...) as this library was built, 0
+ * for a name it does not know: lets a foreign-function binding check its mirror of the
+ * layouts before it passes one across (tests/test_config.py does, for the ctypes mirror). */
+size_t mifsk_abi_sizeof( const char *name );
 
 /* ---- N independent fsk_find_frame() problems --------------------------- */
 

@@ -202,7 +202,7 @@ EXPORTS = [
     "fsk_set_tones_by_bandshift",
     "mifsk_modem_args_default", "mifsk_rx_config_init", "mifsk_max_frames",
     "mifsk_stream_padding", "mifsk_ctx_create", "mifsk_ctx_destroy",
-    "mifsk_ctx_device_name", "mifsk_abi_version", "mifsk_find_frame_batch", "mifsk_demod_plan_ex",
+    "mifsk_ctx_device_name", "mifsk_abi_version", "mifsk_abi_sizeof", "mifsk_find_frame_batch", "mifsk_demod_plan_ex",
     "mifsk_demod_batch", "mifsk_demod_batch_host",
     "mifsk_tx_tone_init", "mifsk_tx_synthesize",
     "mifsk_databits_create", "mifsk_databits_destroy", "mifsk_databits_reset",
@@ -240,6 +240,8 @@ def load():
     lib.mifsk_ctx_device_name.restype = C.c_char_p
     lib.mifsk_ctx_device_name.argtypes = [C.c_void_p]
     lib.mifsk_abi_version.restype = C.c_int
+    lib.mifsk_abi_sizeof.restype = C.c_size_t
+    lib.mifsk_abi_sizeof.argtypes = [C.c_char_p]
     lib.mifsk_find_frame_batch.restype = C.c_int
     lib.mifsk_find_frame_batch.argtypes = [C.c_void_p, C.POINTER(RxConfig), C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]

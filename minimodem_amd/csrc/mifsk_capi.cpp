@@ -354,6 +354,29 @@ int mifsk::ctx_device( const mifsk_ctx *ctx ) { return ctx->device; }
 
 extern "C" int mifsk_abi_version( void ) { return MIFSK_ABI_VERSION; }
 
+extern "C" size_t mifsk_abi_sizeof( const char *name )
+{
+    if ( !name )
+	return 0;
+#define MIFSK_SIZEOF(T) if ( std::strcmp(name, #T) == 0 ) return sizeof(T)
+    MIFSK_SIZEOF(mifsk_modem_args);
+    MIFSK_SIZEOF(mifsk_rx_config);
+    MIFSK_SIZEOF(mifsk_search);
+    MIFSK_SIZEOF(mifsk_search_result);
+    MIFSK_SIZEOF(mifsk_frame);
+    MIFSK_SIZEOF(mifsk_episode);
+    MIFSK_SIZEOF(mifsk_demod_io);
+    MIFSK_SIZEOF(mifsk_launch_info);
+    MIFSK_SIZEOF(mifsk_scan_plan);
+    MIFSK_SIZEOF(mifsk_host_stats);
+    MIFSK_SIZEOF(mifsk_stream_state);
+    MIFSK_SIZEOF(mifsk_wav_info);
+    MIFSK_SIZEOF(mifsk_file_result);
+    MIFSK_SIZEOF(fsk_plan);
+#undef MIFSK_SIZEOF
+    return 0;
+}
+
 extern "C" int mifsk_ctx_create( mifsk_ctx **out, int device )
 {
     if ( !out )

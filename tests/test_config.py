@@ -153,6 +153,20 @@ def test_scan_plans_cover_their_windows():
 
 
 def test_struct_layouts_match_between_bindings():
+    # the ctypes mirror against the library's own sizeof() of every public struct
+    import minimodem_amd as M
+    lib = _lib.load()
+    mirror = {"mifsk_modem_args": _lib.ModemArgs, "mifsk_rx_config": _lib.RxConfig, "mifsk_search": _lib.Search,
+              "mifsk_search_result": _lib.SearchResult, "mifsk_demod_io": _lib.DemodIO,
+              "mifsk_launch_info": _lib.LaunchInfo, "mifsk_scan_plan": _lib.ScanPlan,
+              "mifsk_host_stats": _lib.HostStats, "mifsk_wav_info": _lib.WavInfo,
+              "mifsk_file_result": _lib.FileResult, "fsk_plan": _lib.FskPlan}
+    for name, t in mirror.items():
+        assert lib.mifsk_abi_sizeof(name.encode()) == C.sizeof(t), name
+    assert lib.mifsk_abi_sizeof(b"mifsk_frame") == M.FRAME_DTYPE.itemsize
+    assert lib.mifsk_abi_sizeof(b"mifsk_episode") == M.EPISODE_DTYPE.itemsize
+    assert lib.mifsk_abi_sizeof(b"mifsk_stream_state") == M.STATE_DTYPE.itemsize
+    assert lib.mifsk_abi_sizeof(b"no such struct") == 0
     assert C.sizeof(_lib.RxConfig) == C.sizeof(O.RxConfig)
     assert C.sizeof(_lib.ModemArgs) == C.sizeof(O.ModemArgs)
 
