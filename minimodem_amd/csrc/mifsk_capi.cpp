@@ -469,6 +469,10 @@ static void cache_gc( mifsk_ctx *ctx )
     }
     std::unique_lock<std::shared_mutex> x(ctx->gate);
     std::lock_guard<std::mutex> g(ctx->lock);
+    // (another caller may have flushed while this one waited for the gate)
+    if ( ctx->configs.size() < kMaxConfigs && ctx->tables.size() < kMaxTables
+	    && ctx->table_bytes < kMaxTableBytes )
+	return;
     (void)hipDeviceSynchronize();
     for ( CfgEntry &e : ctx->configs ) {
 	(void)hipFree(e.dev);
@@ -501,7 +505,10 @@ static int get_twiddles( mifsk_ctx *ctx, const TwKey &key, const double **d_out 
     }
     double *d = nullptr;
     HIP_OK(hipMalloc(&d, h.size() * sizeof(double)));
-    HIP_OK(hipMemcpy(d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+    if ( hipMemcpy(d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ) {
+	(void)hipFree(d);
+	return -EIO;
+    }
     ctx->tables.push_back(TwEntry{key, d});
     ctx->table_bytes += h.size() * sizeof(double);
     *d_out = d;
@@ -519,10 +526,16 @@ static int get_devcfg( mifsk_ctx *ctx, const DevCfg &d, const DevCfg **d_out, Cf
 	}
     DevCfg *dev = nullptr;
     HIP_OK(hipMalloc(&dev, sizeof(DevCfg)));
-    HIP_OK(hipMemcpy(dev, &d, sizeof(DevCfg), hipMemcpyHostToDevice));
+    if ( hipMemcpy(dev, &d, sizeof(DevCfg), hipMemcpyHostToDevice) != hipSuccess ) {
+	(void)hipFree(dev);
+	return -EIO;
+    }
     CfgEntry ce;
     ce.host = d;
     ce.dev = dev;
+    size_t rot_bytes = 0;
+    for ( int k = 0; k < 5; k++ )
+	ce.d_rot[k] = nullptr;
     // shared segments: every window's rotation factors, [segment of the window][window]
     for ( int k = 0; k < 5; k++ ) {
 	ce.d_rot[k] = nullptr;
@@ -543,11 +556,17 @@ static int get_devcfg( mifsk_ctx *ctx, const DevCfg &d, const DevCfg **d_out, Cf
 		twiddle(d.b_space, off, d.fftsize, t + 2);
 	    }
 	if ( hipMalloc(&ce.d_rot[k], h.size() * sizeof(double)) != hipSuccess
-		|| hipMemcpy(ce.d_rot[k], h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess )
+		|| hipMemcpy(ce.d_rot[k], h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ) {
+	    // nothing of a half-made entry stays behind
+	    for ( int j = 0; j <= k; j++ )
+		if ( ce.d_rot[j] ) (void)hipFree(ce.d_rot[j]);
+	    (void)hipFree(dev);
 	    return -ENOMEM;
+	}
 	ce.rot_stride[k] = stride;
-	ctx->table_bytes += h.size() * sizeof(double);
+	rot_bytes += h.size() * sizeof(double);
     }
+    ctx->table_bytes += rot_bytes;
     ctx->configs.push_back(ce);
     *d_out = dev;
     if ( entry_out ) *entry_out = ce;
@@ -762,8 +781,11 @@ static int demod_batch_wave( mifsk_ctx *ctx, const mifsk_rx_config *cfg, const D
 	if ( rc == 0 && li.chain_groups ) {
 	    std::lock_guard<std::mutex> one(ctx->chain_lock);
 	    rc = chain_prepare(ctx, ns);
-	    if ( rc )
+	    if ( rc ) {
+		if ( scratch_tw ) (void)hipFreeAsync(scratch_tw, st);
+		if ( scratch_ring ) (void)hipFreeAsync(scratch_ring, st);
 		return rc;
+	    }
 	    ha.chain = &ctx->chain;
 	    rc = mifsk::launch_demod_wave(d, d_cfg, d_tw, *io, ha, stream);
 	    // (the caller's stream has joined the groups' by now: freed in stream order behind them)

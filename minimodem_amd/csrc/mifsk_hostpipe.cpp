@@ -29,6 +29,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -327,9 +328,11 @@ int run_job( mifsk_ctx *ctx, Job &job )
     }
 
     const unsigned nthreads = staging_threads();
+    const char *fault_tag = std::getenv("MIFSK_TEST_FAULT_READ");
+    if ( fault_tag && !*fault_tag )
+	fault_tag = nullptr;
     double t_stage = 0.0;
     uint64_t bytes_in = 0, bytes_out = 0;
-    int first_err = 0;
 
     auto copy_out = [&]( size_t ci ) -> int {		// results of chunk ci -> host, on s_out
 	const Chunk &c = chunks[ci];
@@ -375,7 +378,6 @@ int run_job( mifsk_ctx *ctx, Job &job )
 	} else {
 	    const double t0 = now_s();
 	    unsigned char *dst = (unsigned char *)w->pin[sl];
-	    std::atomic<int> err(0);
 	    parallel_for(r, nthreads, [&]( size_t i ) {
 		const Row &row = job.rows[c.lo + i];
 		unsigned char *d = dst + i * c.stride * esz;
@@ -384,16 +386,20 @@ int run_job( mifsk_ctx *ctx, Job &job )
 		} else if ( row.n ) {
 		    const int fd = open(row.path, O_RDONLY | O_CLOEXEC);
 		    int e = fd < 0 ? -errno : read_fully(fd, d, (size_t)row.n * esz, row.off);
+		    // (fault injection for tests/test_gpu_files.py: a file that shrinks between
+		    // its header and its samples cannot be staged without a race)
+		    if ( fault_tag && std::strstr(row.path, fault_tag) )
+			e = -EIO;
 		    if ( fd >= 0 ) close(fd);
 		    if ( e ) {
+			// this file's error (a file that shrank after its header was read, a
+			// read error): reported through its own row, the batch goes on with
+			// a row of zeros in its place
 			std::memset(d, 0, (size_t)row.n * esz);
 			if ( row.err ) *row.err = e;
-			err.store(e);
 		    }
 		}
 	    });
-	    if ( err.load() && !first_err )
-		first_err = err.load();
 	    t_stage += now_s() - t0;
 	    src = dst;
 	    src_pitch_bytes = c.stride * esz;
@@ -401,7 +407,12 @@ int run_job( mifsk_ctx *ctx, Job &job )
 	for ( size_t i = 0; i < r; i++ )
 	    w->pin_n[sl][i] = job.rows[c.lo + i].n;
 	// ---- host -> device
-	const size_t width = std::min(src_pitch_bytes, c.stride * esz);
+	size_t width = std::min(src_pitch_bytes, c.stride * esz);
+	if ( direct && nrows == 1 ) {
+	    // a lone row's stride means nothing (its length is not clipped to it either)
+	    width = (size_t)job.rows[0].n * esz;
+	    src_pitch_bytes = c.stride * esz;
+	}
 	if ( src_pitch_bytes == c.stride * esz )	// rows back to back on both sides: one linear copy
 	    HIP_OK(hipMemcpyAsync(s.d_in, src, width * r, hipMemcpyHostToDevice, w->s_in));
 	else
@@ -463,7 +474,7 @@ int run_job( mifsk_ctx *ctx, Job &job )
 	st.streams += (uint32_t)nrows;
 	st.source_pinned = direct ? 1u : 0u;
     }
-    return first_err;
+    return 0;		// (what a row could not read is in its own error slot)
 }
 
 } // namespace
@@ -504,6 +515,7 @@ extern "C" int mifsk_demod_batch_host_ex( mifsk_ctx *ctx, const mifsk_rx_config 
 	return 0;
     if ( !hio->d_samples )
 	return -EINVAL;
+    try {		// (no exception crosses the C ABI)
     Job job;
     job.cfg = cfg;
     job.s16 = ( hio->flags & MIFSK_IO_HOST_S16 ) != 0;
@@ -526,6 +538,11 @@ extern "C" int mifsk_demod_batch_host_ex( mifsk_ctx *ctx, const mifsk_rx_config 
 	r.err = nullptr;
     }
     return mifsk::run_job(ctx, job);
+    } catch ( const std::bad_alloc & ) {
+	return -ENOMEM;
+    } catch ( ... ) {
+	return -EIO;
+    }
 }
 
 extern "C" int mifsk_demod_batch_host( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
@@ -567,15 +584,9 @@ extern "C" size_t mifsk_max_episodes( const mifsk_rx_config *cfg, size_t nsample
     return nsamples / ( adv + 21 * ( tm ? tm : 1 ) ) + 2;
 }
 
-extern "C" int mifsk_demod_files( mifsk_ctx *ctx, const mifsk_modem_args *args,
-	const char *const *paths, int nfiles, float rxnoise, unsigned flags, mifsk_files **out )
+static int demod_files_impl( mifsk_ctx *ctx, const mifsk_modem_args *args,
+	const char *const *paths, int nfiles, float rxnoise, unsigned flags, mifsk_files *F )
 {
-    if ( !ctx || !args || !out || nfiles < 0 || ( nfiles && !paths ) )
-	return -EINVAL;
-    *out = nullptr;
-    mifsk_files *F = new (std::nothrow) mifsk_files();
-    if ( !F )
-	return -ENOMEM;
     std::memset(&F->stats, 0, sizeof(F->stats));
     F->files.resize((size_t)nfiles);
     F->paths.resize((size_t)nfiles);
@@ -634,6 +645,32 @@ extern "C" int mifsk_demod_files( mifsk_ctx *ctx, const mifsk_modem_args *args,
 	    it = index.emplace(key, F->groups.size() - 1).first;
 	}
 	F->groups[it->second].members.push_back(i);
+    }
+    // ---- length classes.  A batch's output arrays (host vectors, device slots, the copies
+    // back) are sized by its LONGEST file, so one hour-long recording among ten thousand short
+    // ones would cost every one of them the long one's capacity.  Each (rate, format) group is
+    // therefore cut, by length, into classes whose longest file is at most twice the shortest:
+    // a class is one batch with its own capacities, at most 2 x what its files need.
+    {
+	std::vector<mifsk_files::Group> classes;
+	for ( mifsk_files::Group &g : F->groups ) {
+	    std::stable_sort(g.members.begin(), g.members.end(), [&]( int a, int b ) {
+		return F->files[(size_t)a].info.nframes < F->files[(size_t)b].info.nframes;
+	    });
+	    size_t lo = 0;
+	    while ( lo < g.members.size() ) {
+		const uint64_t shortest = std::max<uint64_t>(F->files[(size_t)g.members[lo]].info.nframes, 4096);
+		size_t hi = lo;
+		while ( hi < g.members.size() && F->files[(size_t)g.members[hi]].info.nframes <= 2 * shortest )
+		    hi++;
+		mifsk_files::Group c;
+		c.cfg = g.cfg;
+		c.members.assign(g.members.begin() + (long)lo, g.members.begin() + (long)hi);
+		classes.push_back(std::move(c));
+		lo = hi;
+	    }
+	}
+	F->groups.swap(classes);
     }
     int rc_all = 0;
     for ( mifsk_files::Group &g : F->groups ) {
@@ -695,9 +732,32 @@ extern "C" int mifsk_demod_files( mifsk_ctx *ctx, const mifsk_modem_args *args,
 	}
     }
     F->stats.seconds_total = mifsk::now_s() - t0;	// headers and grouping included
+    // a file that could not be read is that file's error (mifsk_file_result.error), not the
+    // batch's: run_job reports only what stopped the pipeline (HIP, allocation)
+    return rc_all;
+}
+
+extern "C" int mifsk_demod_files( mifsk_ctx *ctx, const mifsk_modem_args *args,
+	const char *const *paths, int nfiles, float rxnoise, unsigned flags, mifsk_files **out )
+{
+    if ( !ctx || !args || !out || nfiles < 0 || ( nfiles && !paths ) )
+	return -EINVAL;
+    *out = nullptr;
+    mifsk_files *F = new (std::nothrow) mifsk_files();
+    if ( !F )
+	return -ENOMEM;
+    int rc;
+    try {		// (no exception crosses the C ABI: the vectors above can throw)
+	rc = demod_files_impl(ctx, args, paths, nfiles, rxnoise, flags, F);
+    } catch ( const std::bad_alloc & ) {
+	delete F;
+	return -ENOMEM;
+    } catch ( ... ) {
+	delete F;
+	return -EIO;
+    }
     *out = F;
-    // a file that could not be read is that file's error, not the batch's
-    return ( rc_all == -ENOMEM || rc_all == -EIO || rc_all == -EINVAL ) ? rc_all : 0;
+    return rc;
 }
 
 extern "C" int mifsk_files_count( const mifsk_files *f ) { return f ? (int)f->files.size() : 0; }

@@ -1124,7 +1124,7 @@ __device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const 
 	StreamLds *lds, const StreamLds::Cmd *cmd, const float *__restrict__ x, uint32_t N,
 	uint32_t region_floats, uint32_t lat_frames, uint32_t wkr, uint32_t done, uint32_t win_base,
 	uint32_t rel_lane, uint32_t safe_limit,
-	float4 (&pbuf)[STAGE_VEC], uint32_t &pref_org4, uint32_t (&wcyc)[3], const TwGroup (&tgr)[3] )
+	float4 (&pbuf)[STAGE_VEC], uint32_t &pref_org4, uint32_t (&wcyc)[6], const TwGroup (&tgr)[3] )
 {
     uint32_t lane = threadIdx.x & 63u;
     asm volatile("" : "+v"(lane));	// per-round values derived from it are recomputed, not spilled
@@ -1176,6 +1176,12 @@ __device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const 
 		pbuf[i] = make_float4(sv.x, sv.y, sv.z, sv.w);
 	    }
 	}
+#ifdef MIFSK_PROFILE
+	// (profile build: the staging phase split into its wait for the round's loads,
+	// the LDS writes, and the issue of the next round's loads)
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+	const uint32_t t_a = MIFSK_CLOCK();
 	// Registers -> LDS.  The store address of vector i is a constant 1 KiB
 	// further on than that of vector i - 1 (an immediate offset, no address
 	// registers).  Vectors beyond nvec are simply not stored.  Only a round
@@ -1208,6 +1214,7 @@ __device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const 
 		    *reinterpret_cast<float4 *>(lane_base + i * 256) = sv;
 	    }
 	}
+	const uint32_t t_b = MIFSK_CLOCK();
 	// The same share of the next round (of this batch or the next), assuming
 	// the lattice goes on; issued unconditionally and with no control flow
 	// after it (see worker_lattice).  (A second, alternating register buffer
@@ -1224,8 +1231,12 @@ __device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const 
 	    }
 	    pref_org4 = ok ? nlo : 0xFFFFFFFFu;
 	}
+	const uint32_t t_c = MIFSK_CLOCK();
 	wave_lds_sync();
 	const uint32_t t_mid = MIFSK_CLOCK();
+	wcyc[3] += t_a - t_in;		// waiting for the round's samples
+	wcyc[4] += t_b - t_a;		// registers -> LDS
+	wcyc[5] += t_c - t_b;		// issuing the next round's loads
 
 	double mr = 0.0, mi = 0.0, sr = 0.0, si = 0.0;
 	if constexpr ( NQ > 0 ) {
@@ -1265,7 +1276,7 @@ __device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const 
 
 __device__ __forceinline__ void worker_lattice_direct( const DevCfg &cfg, const double *__restrict__ tw,
 	StreamLds *lds, const StreamLds::Cmd *cmd, const float *__restrict__ x, uint32_t N,
-	uint32_t lat_frames, uint32_t wkr, uint32_t done, uint32_t win_base, uint32_t (&wcyc)[3] )
+	uint32_t lat_frames, uint32_t wkr, uint32_t done, uint32_t win_base, uint32_t (&wcyc)[6] )
 {
     const uint32_t t_in = MIFSK_CLOCK();
     const uint32_t lane = threadIdx.x & 63u;
@@ -1345,7 +1356,7 @@ __device__ __forceinline__ void worker_main( const DevCfg *__restrict__ cfgp,
 	    tgr[gi] = tw_group_load(tw, (uint32_t)gi, threadIdx.x & 63u);
     }
     uint32_t pref_org4 = 0xFFFFFFFFu;
-    uint32_t wcyc[3] = { 0, 0, 0 };
+    uint32_t wcyc[6] = { 0, 0, 0, 0, 0, 0 };
     for ( uint32_t seq = 0; ; seq++ ) {
 	const uint32_t t_b = MIFSK_CLOCK();
 	lds_barrier();			// command number `seq` has been published
@@ -1388,9 +1399,10 @@ __device__ __forceinline__ void worker_main( const DevCfg *__restrict__ cfgp,
     }
 #ifdef MIFSK_PROFILE
     if ( threadIdx.x == 64 && counters ) {
-	counters[13] = wcyc[0];
-	counters[14] = wcyc[1];
-	counters[15] = wcyc[2];
+	// (high words: the staging phase's parts -- tools/counters.py splits them)
+	counters[13] = wcyc[0] | ( (uint64_t)wcyc[3] << 32 );
+	counters[14] = wcyc[1] | ( (uint64_t)wcyc[4] << 32 );
+	counters[15] = wcyc[2] | ( (uint64_t)wcyc[5] << 32 );
     }
 #else
     (void)counters;

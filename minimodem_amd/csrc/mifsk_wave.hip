@@ -1103,6 +1103,10 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 	const mifsk_stream_state st = au.d_state[s];
 	if ( st.flags & MIFSK_STATE_FINISHED ) {
 	    resumable = false;			// nothing more to do for this stream
+	    // (a stream whose loop was aborted stays aborted for its caller; a chained launch's
+	    // later chunks leave the status word the failed chunk wrote alone -- below)
+	    if ( au.append == 0u )
+		status |= st.status & MIFSK_STREAM_ABORTED;
 	} else if ( st.flags & MIFSK_STATE_STARTED ) {
 	    if ( st.base < origin || st.base - origin > (uint64_t)N || st.rp < st.base ) {
 		status |= MIFSK_STREAM_ABORTED;	// the caller dropped samples the loop still needs
@@ -1569,6 +1573,13 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 	st.nbytes_total = b0 + n_out_bytes;
 	st.nepisodes_total = e0 + n_out_eps;
 	st.status = au.d_state[s].status | status;
+	au.d_state[s] = st;
+    } else if ( stateful && t0 && ( status & MIFSK_STREAM_ABORTED ) ) {
+	// aborted in this call: no later call (or chunk of a chained launch) resumes the
+	// stream from the state of the call before and re-emits over the same outputs
+	mifsk_stream_state st = au.d_state[s];
+	st.flags |= MIFSK_STATE_STARTED | MIFSK_STATE_FINISHED;
+	st.status |= MIFSK_STREAM_ABORTED;
 	au.d_state[s] = st;
     }
     if ( carrier && !paused && resumable ) {			// minimodem.c:1469-1474

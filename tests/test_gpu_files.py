@@ -188,6 +188,38 @@ def test_pipelined_host_entry_over_several_chunks(gpu, fmt, pinned):
         M.host_free(host)
 
 
+def test_unreadable_file_is_its_own_error_and_lengths_are_classed(gpu, tmp_path, monkeypatch):
+    """(1) a file whose samples cannot be read after its header was parsed (it
+    shrank, pread failed) fails alone -- mifsk_demod_files returns 0 and the other files are
+    decoded; (2) one long recording among short ones does not size everybody's output arrays:
+    the batch is cut into length classes, every file still equals the oracle."""
+    M, torch, ctx = gpu
+    rng = np.random.default_rng(77)
+    files = _make_files(M, str(tmp_path), 24, rng)
+    # one recording 40 x longer than the rest
+    cfg = M.rx_config("1200")
+    words = rng.integers(32, 127, size=3000, dtype=np.uint8)
+    x = M.synthesize(cfg, words, leading_silence=100)
+    long_path = os.path.join(str(tmp_path), "long.wav")
+    O.write_wav(long_path, x, 48000, False)
+    files.append((long_path, x, 48000, False))
+    bad = files[5][0]
+    os.rename(bad, bad.replace("f0005", "shrunk0005"))
+    files[5] = (bad.replace("f0005", "shrunk0005"),) + files[5][1:]
+    monkeypatch.setenv("MIFSK_TEST_FAULT_READ", "shrunk")
+    res, stats = M.demod_files(ctx, [f[0] for f in files], "1200")
+    assert len(res) == len(files)
+    ocfg = O.oracle_config("1200")
+    for i, (path, x, rate, s16) in enumerate(files):
+        if "shrunk" in path:
+            assert res[i]["error"] == -5, res[i]["error"]        # -EIO, this file only
+            continue
+        assert res[i]["error"] == 0, (path, res[i]["error"])
+        ref = O.oracle_rx_stream(ocfg, x, ring_mode=False)
+        assert bytes(res[i]["bytes"]) == bytes(ref["bytes"]), path
+    assert len(res[-1]["bytes"]) == 3000
+
+
 def test_cli_decodes_a_list_of_files_as_one_batch(gpu, tmp_path):
     """`minimodem_mifsk_batch --rx --file a --file b ... 1200`: the batch binding as a program
     (csrc/mifsk_cli.c over mifsk_demod_files), against the reference run once per file."""

@@ -45,13 +45,25 @@ def main():
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record(); M.demod_batch(ctx, cfg, d, nsamples=lens, want=("bytes", "counters"), out=out, engine=args.engine); e1.record()
         torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
-    c = out["counters"].cpu().numpy().astype(np.float64)
+    raw0 = out["counters"].cpu().numpy().view(np.uint64)
+    # the worker's three counters carry the staging phase's parts in their high words
+    # (profile build, linear rounds): wait for the round's samples / registers -> LDS /
+    # issue of the next round's loads
+    hi = {13: "w_stage_wait", 14: "w_stage_write", 15: "w_stage_issue"}
+    hiv = {k: (raw0[:, k] >> np.uint64(32)).astype(np.float64) for k in hi}
+    c = (raw0 & np.uint64(0xFFFFFFFF)).astype(np.float64)
+    for k in range(c.shape[1]):
+        if k not in hi:
+            c[:, k] = raw0[:, k].astype(np.float64)
     nf = out["nframes"].cpu().numpy()
     print("%s: streams %d  frames/stream mean %.1f  kernel %.3f ms" % (args.config, n, nf.mean(), float(np.median(ts))))
     for idx, name in sorted(M.COUNTER_NAMES.items()):
         col = c[:, idx]
         if col.max() > 0:
             print("%-16s mean %12.1f  min %12.0f  max %12.0f" % (name, col.mean(), col.min(), col.max()))
+    for k, name in hi.items():
+        if hiv[k].max() > 0:
+            print("%-16s mean %12.1f  min %12.0f  max %12.0f" % (name, hiv[k].mean(), hiv[k].min(), hiv[k].max()))
     raw = out["counters"].cpu().numpy().view(np.uint64)
     if (raw[:, 23] != 0).any():
         # where the streams sit inside the launch: start and end of each on the chip-wide
