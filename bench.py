@@ -210,10 +210,30 @@ def hbm_traffic(name):
         return None
 
 
-def run_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, cpu_leg):
+class RankFailed(RuntimeError):
+    """some rank (maybe not this one) failed in a phase every rank has now left"""
+
+
+def agree(torch, dist, err, what):
+    """Every rank calls this at the end of a phase with its own exception (or None): an
+    all-reduce of the failure flag, so that either all ranks go on or all raise RankFailed --
+    a rank that threw never leaves the others waiting inside a collective it skipped."""
+    flag = 1.0 if err is not None else 0.0
+    if dist is not None:
+        t = torch.tensor([flag], dtype=torch.float64, device="cuda" if torch.cuda.is_available() else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        flag = float(t.item())
+    if flag:
+        raise RankFailed("%s: %s" % (what, repr(err) if err is not None else "another rank failed"))
+
+
+def run_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, cpu_leg, oracle_leg=True):
     """One BASELINE entry on this rank's shard: synthesize the batch on the device (or host for
     configs[1]), W untimed + K timed passes bracketed by barrier + synchronize, kernel time by
-    events on the launch stream.  Returns the JSON line as a dict on rank 0, None elsewhere."""
+    events on the launch stream.  Returns the JSON line as a dict on rank 0, None elsewhere.
+    Collective-safe: the phases that can fail on one rank alone (allocation, synthesis, a
+    launch) end in agree(); inside the timed loop a rank whose launch failed still takes part
+    in every gather and reports afterwards."""
     entry, mode, per_gpu, seconds, _, amplitude = WORKLOADS[name]
     cfg = M.rx_config(mode)
     per_gpu = args.streams or per_gpu
@@ -228,6 +248,32 @@ def run_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, cp
 
     # ---- synthetic batch, resident in HBM before anything is timed ----------
     payloads = [None] * nstreams
+    setup_err = None
+    samples = lens = bufs = None
+    try:
+        samples, lens = make_batch(name, M, torch, ctx, cfg, rank, lo, nstreams, nsamp, stride, amplitude, payloads)
+        torch.cuda.synchronize()
+    except Exception as e:				# noqa: BLE001 -- reported through agree()
+        setup_err = e
+    agree(torch, dist, setup_err, "%s: batch synthesis" % name)
+    total_samples_local = float(nstreams * nsamp if lens is None else int(lens.sum()))
+
+    frames_cap = M.max_frames(cfg, stride)
+    want = ("bytes",)
+    kw = dict(want=want, frames_cap=frames_cap, nsamples=lens, engine=args.engine, episodes_cap=8)
+    try:
+        bufs = [M.demod_batch(ctx, cfg, samples, **kw) for _ in range(2)]
+        torch.cuda.synchronize()
+    except Exception as e:				# noqa: BLE001
+        setup_err = e
+    agree(torch, dist, setup_err, "%s: first launch" % name)
+    return timed_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, cpu_leg, oracle_leg,
+                          cfg, mode, entry, samples, lens, bufs, kw, payloads, lo, nstreams, nsamp, stride,
+                          frames_cap, total_streams, total_samples_local)
+
+
+def make_batch(name, M, torch, ctx, cfg, rank, lo, nstreams, nsamp, stride, amplitude, payloads):
+    """the rank's shard of the synthetic batch -> (samples on the device, lengths or None)"""
     if name == "1200":
         # host generator (threaded; it releases the GIL)
         host = np.zeros((nstreams, stride), np.float32)
@@ -266,27 +312,70 @@ def run_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, cp
                     rows += torch.randn(rows.shape, generator=g, device="cuda", dtype=torch.float32) * sigma
                 elif kind == "dc":
                     rows -= np.float32(v)
-    torch.cuda.synchronize()
-    total_samples_local = float(nstreams * nsamp if lens is None else int(lens.sum()))
+    return samples, lens
 
-    frames_cap = M.max_frames(cfg, stride)
-    want = ("bytes",)
-    kw = dict(want=want, frames_cap=frames_cap, nsamples=lens, engine=args.engine, episodes_cap=8)
-    bufs = [M.demod_batch(ctx, cfg, samples, **kw) for _ in range(2)]
-    torch.cuda.synchronize()
 
+def oracle_verdict(name, mode, M, torch, ctx, cfg, samples, lens, kw, frames_cap, lo, world):
+    """One more (untimed) pass that also writes frame records and episodes, then the oracle
+    over every stream of the shard (tests/_oracle.py oracle_batch_mismatches).  Never raises:
+    a checker that could not run says so in the line."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import _oracle as O
+        k2 = dict(kw)
+        k2["want"] = ("bytes", "frames", "episodes")
+        k2["episodes_cap"] = 64
+        out = M.demod_batch(ctx, cfg, samples, **k2)
+        torch.cuda.synchronize()
+        res = M.results_to_host(out)
+        del out
+        threads = max(1, (os.cpu_count() or 1) // max(1, world))
+        groups = (lambda i: (lo + i) % 8) if name == "same" else None
+        t0 = time.perf_counter()
+        bad, by_group, secs = O.oracle_batch_mismatches(O.oracle_config(mode), samples, lens, res,
+                                                        threads=threads, groups=groups)
+        v = {"streams": int(samples.shape[0]), "mismatching_streams": len(bad),
+             "compared": "every stream: nframes, frame records (bits, start, flags, confidence and "
+                         "amplitude bit patterns), episodes, bytes",
+             "threads": threads, "oracle_seconds": secs, "seconds": time.perf_counter() - t0}
+        if bad:
+            v["first_mismatching"] = [int(lo + i) for i in bad[:8]]
+        if by_group:
+            v["frames_equal_oracle_by_condition"] = {int(k): "%d/%d" % tuple(c) for k, c in sorted(by_group.items())}
+        return v
+    except Exception as e:					# noqa: BLE001
+        return {"streams": int(samples.shape[0]), "mismatching_streams": None, "error": repr(e)}
+
+
+def timed_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, cpu_leg, oracle_leg,
+                   cfg, mode, entry, samples, lens, bufs, kw, payloads, lo, nstreams, nsamp, stride,
+                   frames_cap, total_streams, total_samples_local):
     pending = [None, None]
-    gatherer = M.ByteGatherer(dist, rank, world)
+    # what a stream can decode at most is known on the host (its length): the gather ships
+    # that many columns, not the whole frames_cap-wide buffer
+    cols = int(M.max_frames(cfg, nsamp if lens is None else int(lens.max())))
+    rows = [M.shard_range(total_streams, r, world)[1] - M.shard_range(total_streams, r, world)[0] for r in range(world)]
+    gatherer = M.ByteGatherer(dist, rank, world, cols=min(cols, frames_cap), rows=rows)
+    failure = [None]
+    wait_s = [0.0]
+
+    def wait_all(ws):
+        t = time.perf_counter()
+        for w in ws:
+            w.wait()
+        wait_s[0] += time.perf_counter() - t
 
     def step(i, events=None):
         b = i & 1
         if pending[b] is not None:		# its buffers are about to be overwritten
-            for w in pending[b]:
-                w.wait()
+            wait_all(pending[b])
             pending[b] = None
         if events is not None:
             events[0].record()
-        M.demod_batch(ctx, cfg, samples, out=bufs[b], **kw)
+        try:
+            M.demod_batch(ctx, cfg, samples, out=bufs[b], **kw)
+        except Exception as e:			# noqa: BLE001 -- this rank still joins every gather
+            failure[0] = failure[0] or e
         if events is not None:
             events[1].record()
         if world > 1:
@@ -296,8 +385,7 @@ def run_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, cp
     def drain():
         for b in (0, 1):
             if pending[b] is not None:
-                for w in pending[b]:
-                    w.wait()
+                wait_all(pending[b])
                 pending[b] = None
 
     for i in range(warmup):
@@ -307,6 +395,7 @@ def run_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, cp
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    wait_s[0] = 0.0
 
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
            for _ in range(steps)]
@@ -319,9 +408,13 @@ def run_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, cp
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # (this rank's own clock stopped after the closing barrier: the same for all; what differs
+    # per rank is how long its launches and its waits for the gather took)
+    agree(torch, dist, failure[0], "%s: timed loop" % name)
 
     kernel_ms = [a.elapsed_time(b) for a, b in evs]
     total_samples = total_samples_local
+    per_rank = None
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -329,10 +422,34 @@ def run_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, cp
         t = torch.tensor([total_samples_local], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         total_samples = float(t.item())
+        # root against peers: if the efficiency at N > 1 is short, this says whether the root
+        # (which also receives N - 1 shards per step) is the slow rank, and by how much
+        mine = torch.tensor([float(np.mean(kernel_ms)), float(np.max(kernel_ms)), wait_s[0] / max(1, steps) * 1e3],
+                            dtype=torch.float64, device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = {"kernel_ms_avg": [float(a[0]) for a in allr], "kernel_ms_max": [float(a[1]) for a in allr],
+                    "gather_wait_ms_per_step": [float(a[2]) for a in allr],
+                    "gather_bytes_per_peer_per_step": gatherer.bytes_per_peer(nstreams)}
 
     last = (steps - 1) & 1 if steps else 0
     res = M.results_to_host(bufs[last])
     gpu_bytes, gpu_nbytes = res["bytes"], res["nbytes"]
+
+    # ---- the checker leg (outside every timed region): the WHOLE shard against the oracle,
+    # frame for frame -- bits, starts, flags, confidence and amplitude bit patterns, episodes,
+    # bytes -- on this box's host cores (every rank checks its own shard on its share of them)
+    oracle = None
+    if oracle_leg:
+        oracle = oracle_verdict(name, mode, M, torch, ctx, cfg, samples, lens, kw, frames_cap, lo, world)
+        if dist is not None:
+            t = torch.tensor([oracle["mismatching_streams"] if oracle.get("error") is None else 0.0,
+                              oracle["streams"], 1.0 if oracle.get("error") else 0.0],
+                             dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            oracle["mismatching_streams_all_ranks"] = int(t[0].item())
+            oracle["streams_all_ranks"] = int(t[1].item())
+            oracle["ranks_failed"] = int(t[2].item())
 
     def stream_ok(b, nb, payload, gid):
         got = b[:nb].tobytes()
@@ -363,6 +480,10 @@ def run_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, cp
                 out += len(got)
             by_condition[label] = {"streams": len(mine), "whole_payload": whole,
                                    "bytes_decoded_over_sent": out / max(1, sent)}
+            if oracle is not None and "frames_equal_oracle_by_condition" in oracle:
+                # the decode error rate vs the ORACLE per condition (streams whose
+                # every frame record equals the oracle's on the identical buffer)
+                by_condition[label]["frames_equal_oracle"] = oracle["frames_equal_oracle_by_condition"].get(k)
     # the bytes gathered from the peers are checked too (rank 0): each peer's streams are
     # regenerated from their global ids
     peers_ok = peers_judged = 0
@@ -415,8 +536,13 @@ def run_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, cp
         }
         if by_condition is not None:
             line["payload_by_condition"] = by_condition
+        if oracle is not None:
+            line["oracle_mismatching_streams"] = (oracle.get("mismatching_streams_all_ranks")
+                                                  if world > 1 else oracle["mismatching_streams"])
+            line["oracle"] = oracle
         if world > 1:
             line["payload_roundtrip_ok_streams_gathered_from_peers"] = "%d/%d" % (peers_ok, peers_judged)
+            line["per_rank"] = per_rank
         if world == 1 and cpu_leg:
             # a bounded sample of the same batch on the host cores
             k = nstreams if name == "1200" else {"rtty": 256, "12000": 1024, "same": 512}[name]
@@ -504,7 +630,8 @@ def main():
                          "with a few steps each under its \"configs\" key)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--streams", type=int, default=0, help="streams per GPU (default: the config's)")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-cpu", action="store_true",
+                    help="skip the CPU legs (the timed baselines and the whole-batch oracle verdict)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the H2D-inclusive leg")
     ap.add_argument("--no-extra", action="store_true", help="configs[1] only: skip configs[2..4]")
     ap.add_argument("--engine", default=None, choices=["wave", "workgroup"],
@@ -554,7 +681,7 @@ def main():
 
     name = args.config or "1200"
     line = run_workload(name, args, M, torch, dist, ctx, rank, world, args.steps, args.warmup,
-                        cpu_leg=not args.no_cpu)
+                        cpu_leg=not args.no_cpu, oracle_leg=not args.no_cpu)
     if args.config is None and not args.no_extra:
         # the other BASELINE entries at their stated per-GPU sizes, a few timed passes each, device
         # generator, no CPU leg: driver-visible kernel time and roofline fraction per entry
@@ -562,9 +689,12 @@ def main():
         for other in ("12000", "same", "rtty"):		# (shortest kernels first, the 12 ms one last)
             try:
                 sub = run_workload(other, args, M, torch, dist, ctx, rank, world,
-                                   max(1, min(5, args.steps)), 1, cpu_leg=False)
-            except Exception as e:				# noqa: BLE001
+                                   max(1, min(5, args.steps)), 1, cpu_leg=False,
+                                   oracle_leg=not args.no_cpu)
+            except RankFailed as e:
+                # (raised on EVERY rank by agree(): nobody is left inside a collective)
                 sub = {"error": repr(e)} if rank == 0 else None
+                torch.cuda.empty_cache()
             if rank == 0 and sub is not None:
                 if "error" in sub:
                     extra[other] = sub
@@ -579,7 +709,11 @@ def main():
                                  "unit": rf["unit"], "frac": rf["frac"], "traffic": rf["traffic"]},
                     "launch": rf["launch"],
                     "payload_roundtrip_ok_streams": sub["payload_roundtrip_ok_streams"],
+                    "oracle_mismatching_streams": sub.get("oracle_mismatching_streams"),
+                    "oracle": sub.get("oracle"),
                 }
+                if "per_rank" in sub:
+                    extra[other]["per_rank"] = sub["per_rank"]
                 if "payload_by_condition" in sub:
                     extra[other]["payload_by_condition"] = sub["payload_by_condition"]
                 if "payload_roundtrip_ok_streams_gathered_from_peers" in sub:

@@ -374,27 +374,54 @@ class ByteGatherer:
     sends on its own link to the root (RCCL over xGMI on GPUs, gloo in the CPU
     tests) -- and returns the work handles; the caller waits on them before it
     reuses the buffers it passed.  On the root, received(r) is the latest
-    (bytes, nbytes) of peer r >= 1 once its handles have been waited on."""
+    (bytes, nbytes) of peer r >= 1 once its handles have been waited on.
 
-    def __init__(self, dist, rank, world):
+    cols: how many columns of the [nstreams, frames_cap] byte buffer can hold
+    data at all (the caller knows its streams' lengths: mifsk_max_frames of the
+    longest) -- only those are shipped, from a narrow staging copy made on the
+    caller's stream (two of them, used alternately like the caller's buffers).
+    rows: streams per rank when the shards differ in size (default: all ranks
+    hold as many as this one)."""
+
+    def __init__(self, dist, rank, world, cols=None, rows=None):
         self.dist, self.rank, self.world = dist, rank, world
+        self.cols, self.rows = cols, rows
         self._rx = None
+        self._tx = [None, None]
+        self._k = 0
+
+    def bytes_per_peer(self, nstreams):
+        """what one peer sends per step (bytes + counts)"""
+        return int(nstreams) * (int(self.cols) if self.cols else 0) + 4 * int(nstreams)
 
     def start(self, local_bytes, local_nbytes):
         dist = self.dist
         if self.world == 1:
             return []
+        cols = local_bytes.shape[1] if self.cols is None else min(int(self.cols), local_bytes.shape[1])
+        self.cols = cols
         if self.rank == 0:
             if self._rx is None:
                 torch = _torch()
-                self._rx = [(torch.empty_like(local_bytes), torch.empty_like(local_nbytes))
-                            for _ in range(self.world - 1)]
+                rows = self.rows or [local_bytes.shape[0]] * self.world
+                self._rx = [(torch.empty((rows[r], cols), dtype=local_bytes.dtype, device=local_bytes.device),
+                             torch.empty((rows[r],), dtype=local_nbytes.dtype, device=local_nbytes.device))
+                            for r in range(1, self.world)]
             ops = []
             for r in range(1, self.world):
                 ops.append(dist.P2POp(dist.irecv, self._rx[r - 1][0], r))
                 ops.append(dist.P2POp(dist.irecv, self._rx[r - 1][1], r))
         else:
-            ops = [dist.P2POp(dist.isend, local_bytes, 0), dist.P2POp(dist.isend, local_nbytes, 0)]
+            tx = local_bytes
+            if cols != local_bytes.shape[1]:
+                b = self._k & 1
+                self._k += 1
+                if self._tx[b] is None:
+                    self._tx[b] = _torch().empty((local_bytes.shape[0], cols), dtype=local_bytes.dtype,
+                                                 device=local_bytes.device)
+                self._tx[b].copy_(local_bytes[:, :cols])
+                tx = self._tx[b]
+            ops = [dist.P2POp(dist.isend, tx, 0), dist.P2POp(dist.isend, local_nbytes, 0)]
         return dist.batch_isend_irecv(ops)
 
     def received(self, r):

@@ -98,9 +98,11 @@ ensure_twiddles( ofsk_plan *p, unsigned int bit_nsamples )
 /* per-bit two-band correlator: reference src/fsk.c:107-174            */
 /* ------------------------------------------------------------------ */
 
+/* the two bins before they are rounded to the FFT's output type (what the tests
+ * that build inputs ON a float rounding boundary need: tests/test_gpu_guard.py) */
 void
-ofsk_bit_dft( ofsk_plan *p, const float *samples, unsigned int bit_nsamples,
-	float out[4] )
+ofsk_bit_dft_f64( ofsk_plan *p, const float *samples, unsigned int bit_nsamples,
+	double out[4] )
 {
     ensure_twiddles(p, bit_nsamples);
     /* the window is the first bit_nsamples inputs of a zero-padded length-
@@ -114,11 +116,23 @@ ofsk_bit_dft( ofsk_plan *p, const float *samples, unsigned int bit_nsamples,
 	sr = fma(x, tw[2], sr);
 	si = fma(x, tw[3], si);
     }
+    out[0] = mr;
+    out[1] = mi;
+    out[2] = sr;
+    out[3] = si;
+}
+
+void
+ofsk_bit_dft( ofsk_plan *p, const float *samples, unsigned int bit_nsamples,
+	float out[4] )
+{
+    double X[4];
+    ofsk_bit_dft_f64(p, samples, bit_nsamples, X);
     /* fftout is an array of float pairs (fftwf_complex) */
-    out[0] = (float)mr;
-    out[1] = (float)mi;
-    out[2] = (float)sr;
-    out[3] = (float)si;
+    out[0] = (float)X[0];
+    out[1] = (float)X[1];
+    out[2] = (float)X[2];
+    out[3] = (float)X[3];
 }
 
 void
@@ -218,7 +232,8 @@ ofsk_frame_analyze( ofsk_plan *p, const float *samples, float samples_per_bit,
 /* sliding search: reference src/fsk.c:449-538                         */
 /* ------------------------------------------------------------------ */
 
-static unsigned int last_n_positions;
+/* (thread-local: the whole-batch parity checks run ofsk_rx_stream on every host core) */
+static __thread unsigned int last_n_positions;
 
 unsigned int ofsk_last_n_positions( void ) { return last_n_positions; }
 

@@ -84,6 +84,8 @@ unsigned int ofsk_last_n_positions( void );
 void ofsk_twiddle( unsigned int b, unsigned int n, unsigned int fftsize, double w[2] );
 
 /* the raw 2-bin correlation of one bit window (before hypotf / scaling) */
+void ofsk_bit_dft_f64( ofsk_plan *p, const float *samples, unsigned int bit_nsamples,
+	double out[4] );	/* the same sums before rounding to float */
 void ofsk_bit_dft( ofsk_plan *p, const float *samples, unsigned int bit_nsamples,
 	float re_im_out[4] /* mark re, mark im, space re, space im */ );
 

@@ -201,6 +201,7 @@ def oracle_lib():
                                          C.POINTER(C.c_uint), C.POINTER(C.c_float),
                                          C.POINTER(C.c_float)]
         lib.ofsk_bit_dft.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p]
+        lib.ofsk_bit_dft_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p]
         lib.ofsk_detect_carrier.restype = C.c_int
         lib.ofsk_detect_carrier.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_float]
         lib.ofsk_set_tones_by_bandshift.argtypes = [C.c_void_p, C.c_uint, C.c_int]
@@ -318,6 +319,67 @@ def oracle_rx_stream(cfg, samples, ring_mode=False):
         "n_find_frame": int(res.n_find_frame),
         "n_positions": int(res.n_positions),
     }
+
+
+def oracle_batch_mismatches(cfg, samples, lens, res, ring_mode=False, chunk_bytes=1 << 30,
+                            threads=None, what=("frames", "episodes", "bytes"), groups=None):
+    """Whole-batch parity: the restated receive loop over EVERY stream of a batch, on all host
+    cores (ofsk_rx_stream is re-entrant and ctypes releases the GIL), compared with a GPU
+    result `res` (numpy arrays from results_to_host: frames / nframes, episodes / nepisodes,
+    bytes / nbytes -- whichever of `what` it holds).  `samples` is a [nstreams, stride] numpy
+    array or torch tensor (device tensors are brought over in chunks of `chunk_bytes`); `lens`
+    the stream lengths (None: the row width).  Returns (indices of mismatching streams,
+    {group: frames equal / streams} if `groups` -- a function of the stream index -- is given,
+    seconds spent in the oracle)."""
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+    oracle_lib()
+    nstreams, stride = int(samples.shape[0]), int(samples.shape[1])
+    if lens is None:
+        lens = np.full(nstreams, stride, np.int64)
+    elif not isinstance(lens, np.ndarray):
+        lens = lens.cpu().numpy()
+    lens = lens.astype(np.int64)
+    threads = threads or (os.cpu_count() or 1)
+    per = max(1, int(chunk_bytes // max(1, stride * 4)))
+    bad, by_group, t_oracle = [], {}, 0.0
+
+    def one(args):
+        i, xi = args
+        ref = oracle_rx_stream(cfg, xi, ring_mode=ring_mode)
+        ok = True
+        if "frames" in what and "frames" in res:
+            nf = int(res["nframes"][i])
+            ok = ok and nf == len(ref["frames"]) and \
+                res["frames"][i, :min(nf, res["frames"].shape[1])].tobytes() == ref["frames"].tobytes()
+        elif "nframes" in res:
+            ok = ok and int(res["nframes"][i]) == len(ref["frames"])
+        if "episodes" in what and "episodes" in res:
+            ne = int(res["nepisodes"][i])
+            m = min(ne, res["episodes"].shape[1])
+            ok = ok and ne == len(ref["episodes"]) and \
+                res["episodes"][i, :m].tobytes() == ref["episodes"][:m].tobytes()
+        if "bytes" in what and "bytes" in res:
+            ok = ok and res["bytes"][i, :int(res["nbytes"][i])].tobytes() == ref["bytes"]
+        return i, ok
+
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        for c0 in range(0, nstreams, per):
+            c1 = min(nstreams, c0 + per)
+            host = samples[c0:c1]
+            if not isinstance(host, np.ndarray):
+                host = host.cpu().numpy()
+            t0 = time.perf_counter()
+            for i, ok in ex.map(one, [(c0 + j, host[j, :int(lens[c0 + j])]) for j in range(c1 - c0)]):
+                if not ok:
+                    bad.append(i)
+                if groups is not None:
+                    g = by_group.setdefault(groups(i), [0, 0])
+                    g[0] += bool(ok)
+                    g[1] += 1
+            t_oracle += time.perf_counter() - t0
+            del host
+    return bad, by_group, t_oracle
 
 
 # ---------------------------------------------------------------------------

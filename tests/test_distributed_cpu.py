@@ -143,6 +143,60 @@ def test_pipelined_gather_as_in_bench():
     assert seen == [[(10 + step, step + 1)] for step in range(5)]
 
 
+def _narrow_worker(rank, world, port, q):
+    """ByteGatherer with `cols` (only the columns that can hold data are shipped, from a
+    staging copy) and unequal shards (`rows`); then bench.py's agree(): one rank's failure
+    becomes RankFailed on EVERY rank instead of a hang in the next collective."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        rows = [4, 3]
+        g = M.ByteGatherer(dist, rank, world, cols=5, rows=rows)
+        seen = []
+        for step in range(3):
+            b = torch.arange(rows[rank] * 16, dtype=torch.int32).reshape(rows[rank], 16).to(torch.uint8) + step
+            n = torch.full((rows[rank],), step + 2, dtype=torch.int32)
+            for w in g.start(b, n):
+                w.wait()
+            if rank == 0:
+                rb, rn = g.received(1)
+                seen.append((tuple(rb.shape), rb[2].tolist(), rn.tolist()))
+        assert g.bytes_per_peer(rows[rank]) == rows[rank] * 5 + 4 * rows[rank]
+        verdict = []
+        for err in (None, RuntimeError("boom") if rank == 1 else None):
+            try:
+                bench.agree(torch, dist, err, "phase")
+                verdict.append("ok")
+            except bench.RankFailed as e:
+                verdict.append("failed:" + ("mine" if "boom" in str(e) else "peer"))
+        dist.barrier()
+        q.put((rank, seen, verdict))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_narrow_gather_unequal_shards_and_failure_agreement():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_narrow_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict((r, (seen, verdict)) for r, seen, verdict in (q.get(timeout=120), q.get(timeout=120)))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    seen0, v0 = got[0]
+    _, v1 = got[1]
+    # rank 1's row 2 is 32 .. 47 (+ step); five columns arrive
+    assert seen0 == [((3, 5), [32 + s, 33 + s, 34 + s, 35 + s, 36 + s], [s + 2] * 3) for s in range(3)]
+    assert v0 == ["ok", "failed:peer"] and v1 == ["ok", "failed:mine"]
+
+
 def test_bench_spawns_its_own_ranks_when_no_launcher_is_around():
     """`python bench.py --gpus 2` without torchrun: bench.py must start the two ranks itself
     (torch.distributed.run on 127.0.0.1) instead of asserting on WORLD_SIZE.  MIFSK_BENCH_DRYRUN
