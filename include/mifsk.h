@@ -420,7 +420,10 @@ typedef struct mifsk_stream_state {
  * arrays (frames in loop order, episodes as they END); mifsk_frame.start and
  * mifsk_episode.first_frame count from the start of the stream.  Any cut of a
  * stream into slabs gives the frames and episodes of the single call, bit for
- * bit.  Flat addressing, wavefront engine.  Asynchronous on `stream`. */
+ * bit.  Flat addressing; io->flags may force an engine (MIFSK_IO_ENGINE_WAVE /
+ * _WORKGROUP), otherwise the library chooses as mifsk_demod_batch does -- the
+ * state record is the same for both, a stream may even change engines between
+ * slabs.  Asynchronous on `stream`. */
 int mifsk_demod_slab( mifsk_ctx *ctx, const mifsk_rx_config *cfg, const mifsk_demod_io *io,
 	mifsk_stream_state *d_state, const uint64_t *d_origin, int final, void *stream );
 

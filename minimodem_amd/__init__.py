@@ -744,9 +744,12 @@ class SlabSession:
     memory between calls, the unconsumed tail of every stream on the host.  Whatever the cuts,
     the concatenated output is the single call's, bit for bit."""
 
-    def __init__(self, ctx, cfg, nstreams, episodes_cap=16):
+    def __init__(self, ctx, cfg, nstreams, episodes_cap=16, engine=None):
+        """engine: None (the library chooses, as demod_batch does), "wave" or "workgroup"; may
+        be changed between feeds (self.engine): the state record is the same for both."""
         torch = _torch()
         self.ctx, self.cfg, self.n = ctx, cfg, int(nstreams)
+        self.engine = engine
         self.episodes_cap = episodes_cap
         self.state = torch.zeros((self.n, STATE_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
         self.origin = np.zeros(self.n, np.uint64)
@@ -797,7 +800,8 @@ class SlabSession:
         io.episodes_cap = self.episodes_cap
         io.d_status = out["status"].data_ptr()
         io.d_carrier_band = out["carrier_band"].data_ptr()
-        io.flags = 0
+        io.flags = (_lib.IO_ENGINE_WORKGROUP if self.engine == "workgroup" else 0) | \
+            (_lib.IO_ENGINE_WAVE if self.engine == "wave" else 0)
         rc = lib.mifsk_demod_slab(self.ctx.handle, C.byref(self.cfg), C.byref(io),
                                   C.c_void_p(self.state.data_ptr()), C.c_void_p(do.data_ptr()),
                                   1 if final else 0, _stream_ptr(torch, stream))

@@ -799,6 +799,40 @@ static int demod_batch_wave( mifsk_ctx *ctx, const mifsk_rx_config *cfg, const D
     return rc;
 }
 
+// The workgroup engine: one call over whole streams (maybe cut into chained launches of its
+// resumable instantiation: the launcher decides by the batch's shape) or, with d_state, one
+// slab of streams that arrive in pieces.
+static int demod_batch_workgroup( mifsk_ctx *ctx, const mifsk_rx_config *cfg, const DevCfg &d,
+	const DevCfg *d_cfg, const double *d_tw, const mifsk_demod_io *io, void *stream,
+	mifsk::LaunchInfo *plan_only = nullptr, mifsk_stream_state *d_state = nullptr,
+	const uint64_t *d_origin = nullptr, bool final = true )
+{
+    mifsk::WgHostArgs wh;
+    std::memset(&wh, 0, sizeof(wh));
+    wh.ncu = ctx->ncu;
+    wh.samplebuf_size = cfg->samplebuf_size;
+    wh.d_state = d_state;
+    wh.d_origin = d_origin;
+    wh.final = final;
+    wh.chain_ok = !d_state && !io->d_counters;
+    if ( plan_only )
+	return mifsk::launch_demod_batch(d, d_cfg, d_tw, *io, stream, plan_only, &wh);
+    if ( wh.chain_ok ) {
+	mifsk::LaunchInfo li;
+	std::memset(&li, 0, sizeof(li));
+	int rc = mifsk::launch_demod_batch(d, d_cfg, d_tw, *io, stream, &li, &wh);
+	if ( rc == 0 && li.chain_groups ) {
+	    std::lock_guard<std::mutex> one(ctx->chain_lock);
+	    rc = chain_prepare(ctx, (size_t)io->nstreams);
+	    if ( rc )
+		return rc;
+	    wh.chain = &ctx->chain;
+	    return mifsk::launch_demod_batch(d, d_cfg, d_tw, *io, stream, nullptr, &wh);
+	}
+    }
+    return mifsk::launch_demod_batch(d, d_cfg, d_tw, *io, stream, nullptr, &wh);
+}
+
 extern "C" int mifsk_demod_batch( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
 	const mifsk_demod_io *io, void *stream )
 {
@@ -838,7 +872,7 @@ extern "C" int mifsk_demod_batch( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
     const bool workgroup = use_workgroup_engine(cfg, d, io->flags);
     if ( !workgroup )
 	return demod_batch_wave(ctx, cfg, d, d_cfg, d_tw, io, stream, nullptr, nullptr, nullptr, true, &tables);
-    return mifsk::launch_demod_batch(d, d_cfg, d_tw, *io, stream);
+    return demod_batch_workgroup(ctx, cfg, d, d_cfg, d_tw, io, stream);
 }
 
 static_assert(sizeof(mifsk_scan_plan) == sizeof(mifsk::SegPlan), "mifsk_scan_plan mirrors SegPlan");
@@ -856,7 +890,8 @@ extern "C" int mifsk_scan_plan_get( const mifsk_rx_config *cfg, int kind, mifsk_
     return 0;
 }
 
-// the same loop for streams that arrive in pieces: state in, state out (wavefront engine)
+// the same loop for streams that arrive in pieces: state in, state out (either engine: the
+// same choice as mifsk_demod_batch makes, the same state record)
 extern "C" int mifsk_demod_slab( mifsk_ctx *ctx, const mifsk_rx_config *cfg, const mifsk_demod_io *io,
 	mifsk_stream_state *d_state, const uint64_t *d_origin, int final, void *stream )
 {
@@ -868,7 +903,10 @@ extern "C" int mifsk_demod_slab( mifsk_ctx *ctx, const mifsk_rx_config *cfg, con
 	return -EINVAL;
     if ( ( io->d_bytes || io->d_bits || io->d_frames ) && io->frames_cap == 0 )
 	return -EINVAL;
-    if ( io->flags & ~MIFSK_IO_ENGINE_WAVE )	// flat addressing, wavefront engine
+    if ( io->flags & ~( MIFSK_IO_ENGINE_WAVE | MIFSK_IO_ENGINE_WORKGROUP ) )	// flat addressing
+	return -EINVAL;
+    if ( ( io->flags & MIFSK_IO_ENGINE_WORKGROUP )
+	    && ( ( io->flags & MIFSK_IO_ENGINE_WAVE ) || cfg->auto_carrier_threshold > 0.0f ) )
 	return -EINVAL;
     HIP_OK(hipSetDevice(ctx->device));
     cache_gc(ctx);
@@ -885,6 +923,10 @@ extern "C" int mifsk_demod_slab( mifsk_ctx *ctx, const mifsk_rx_config *cfg, con
     rc = get_devcfg(ctx, d, &d_cfg, &tables);
     if ( rc )
 	return rc;
+    if ( io->nstreams == 0 )
+	return 0;
+    if ( use_workgroup_engine(cfg, d, io->flags) )
+	return demod_batch_workgroup(ctx, cfg, d, d_cfg, d_tw, io, stream, nullptr, d_state, d_origin, final != 0);
     return demod_batch_wave(ctx, cfg, d, d_cfg, d_tw, io, stream, nullptr, d_state, d_origin, final != 0, &tables);
 }
 
@@ -910,7 +952,7 @@ extern "C" int mifsk_demod_plan_ex( mifsk_ctx *ctx, const mifsk_rx_config *cfg, 
     mifsk::LaunchInfo li;
     std::memset(&li, 0, sizeof(li));
     const bool workgroup = use_workgroup_engine(cfg, d, flags);
-    int rc = workgroup ? mifsk::launch_demod_batch(d, nullptr, nullptr, io, nullptr, &li)
+    int rc = workgroup ? demod_batch_workgroup(ctx, cfg, d, nullptr, nullptr, &io, nullptr, &li)
 		       : demod_batch_wave(ctx, cfg, d, nullptr, nullptr, &io, nullptr, &li);
     if ( rc )
 	return rc;

@@ -126,8 +126,25 @@ struct LaunchInfo {
     uint32_t	chain_groups, chain_chunks;	// chained launches (WaveChain): groups of streams x time chunks; 0 = one launch
 };
 
+struct WaveChain;
+// what the host glue hands the workgroup engine's launcher besides cfg / io: the loop state of
+// streams that arrive in pieces (mifsk_demod_slab) and what a chained launch needs (the
+// wavefront engine's WaveHostArgs carries the same)
+struct WgHostArgs {
+    int		ncu;		// compute units of the device
+    uint32_t	samplebuf_size;
+    mifsk_stream_state *d_state;	// mifsk_demod_slab: state in / out (nullptr: one call = whole streams)
+    const uint64_t *d_origin;
+    bool	final;
+    // non-NULL: the launcher may chain (it decides by the batch's shape); the caller holds
+    // whatever serialises the chain's users.  chain_ok: what a plan-only call assumes
+    const WaveChain *chain;
+    bool	chain_ok;
+};
+
 int launch_demod_batch( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_tw,
-	const mifsk_demod_io &io, void *stream, LaunchInfo *plan_only = nullptr );
+	const mifsk_demod_io &io, void *stream, LaunchInfo *plan_only = nullptr,
+	const WgHostArgs *wh = nullptr );
 
 // ---- one wavefront per stream (mifsk_wave.hip) ---------------------------
 

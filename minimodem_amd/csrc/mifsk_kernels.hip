@@ -31,6 +31,8 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <cstdio>
+#include <cstring>
 
 #include "mifsk_device.h"
 #include "mifsk_devmath.h"
@@ -690,11 +692,24 @@ struct Master {
 // kernel stores can change *cfgp, and without that every configuration read inside the loop
 // is a vector load plus v_readfirstlane instead of a scalar load (measured with a struct
 // parameter: configs[1] 0.45 -> 0.54 ms, 12000 baud 1.29 -> 1.89 ms).
+// streams that arrive in pieces (mifsk_demod_slab) and chained launches: what the resumable
+// instantiation demod_kernel<., ., ., true> needs beyond the batch itself (DESIGN.md 4.10,
+// 4.11; the wavefront engine's WaveAuto carries the same five)
+struct WgResume {
+    mifsk_stream_state	*d_state;	// [nstreams] or null (then the kernel behaves as the plain one)
+    const uint64_t	*d_origin;	// [nstreams] index of each row's first sample in its stream, or null
+    uint32_t		final;		// no more samples will follow these rows
+    uint32_t		limit;		// chained launch: this call sees the first `limit` samples of a row (0: all)
+    uint32_t		append;		// chained launch: outputs continue behind the chunk before
+    uint32_t		bufsize;	// the reference's samplebuf_size (minimodem.c:1056-1069)
+};
+
 struct DemodArgs {
     const DevCfg	*cfgp;
     const double	*tw;
     mifsk_demod_io	io;
     uint32_t		slab_cap, lat_frames, lat_rounds, region_floats, region_cap, lat_mode;
+    WgResume		rs;
 };
 
 // where stream s writes its results.  Made once: the serial loop is latency-bound,
@@ -711,16 +726,24 @@ struct StreamOut {
 
 
 // The reference's receive loop (minimodem.c:1137-1463); executed by wave 0 only.
-template <bool USE_SLAB, int NQ>
+template <bool USE_SLAB, int NQ, bool ST>
 __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__restrict__ tw,
 	const mifsk_demod_io &io, uint32_t slab_cap, uint32_t lat_frames, uint32_t lat_round,
-	uint32_t lat_mode, uint32_t base0, StreamLds *lds )
+	uint32_t lat_mode, uint32_t base0, StreamLds *lds, const WgResume &rs )
 {
     const uint32_t s = blockIdx.x;
     const float *x = io.d_samples + (size_t)s * io.stream_stride;
     uint32_t N = io.d_nsamples ? io.d_nsamples[s] : io.nsamples;
     if ( io.nstreams > 1 && (size_t)N > io.stream_stride )
 	N = (uint32_t)io.stream_stride;		// never trust a length beyond the row
+    // chained launches: this call takes the stream up to rs.limit only
+    bool cut = false;
+    if constexpr ( ST ) {
+	if ( rs.d_state && rs.limit != 0u && rs.limit < N ) {
+	    N = rs.limit;
+	    cut = true;
+	}
+    }
 
     StreamOut o;
     o.fcap = io.frames_cap;
@@ -750,7 +773,73 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 
     uint32_t base = base0 < N ? base0 : N;	// absolute index of samplebuf[0]
     uint32_t n_out_frames = 0, n_out_bytes = 0, n_out_eps = 0, ep_first = 0;
+    uint32_t ep_b_mark = 0;			// (carried in the state record only)
     uint32_t status = 0;
+
+    // mifsk_demod_slab / chained launches (ST): this row is the stream from index `origin`
+    // on, the loop resumes from the state the call before left (minimodem.c:1079-1088,
+    // 1132-1133,1144-1174).  Same rules, same state record as the wavefront engine
+    // (demod_wave_kernel<., ., true>): positions inside the kernel are relative to the row;
+    // what leaves it (frame starts, episode frame indices, the saved state) counts from the
+    // start of the stream.  `rp` is the reference's file position: base + samples_nvalid.
+    const bool stateful = ST && rs.d_state != nullptr;
+    const bool last_slab = !stateful || rs.final != 0u || ( rs.limit != 0u && !cut );
+    uint64_t origin = 0;
+    uint32_t frame_base = 0;			// frames emitted by the calls before
+    bool resumable = true;
+    uint32_t rp = base;
+    if constexpr ( ST ) {
+	if ( stateful ) {
+	    if ( rs.d_origin )
+		origin = rs.d_origin[s];
+	    const mifsk_stream_state st = rs.d_state[s];
+	    if ( st.flags & MIFSK_STATE_FINISHED ) {
+		resumable = false;			// nothing more to do for this stream
+		if ( rs.append == 0u )
+		    status |= st.status & MIFSK_STREAM_ABORTED;
+	    } else if ( st.flags & MIFSK_STATE_STARTED ) {
+		if ( st.base < origin || st.base - origin > (uint64_t)N || st.rp < st.base ) {
+		    status |= MIFSK_STREAM_ABORTED;	// the caller dropped samples the loop still needs
+		    resumable = false;
+		} else {
+		    // (the record was read with vector loads: every field goes through
+		    // v_readfirstlane so that the loop state stays in scalar registers)
+		    auto u32 = []( uint32_t v ) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+		    auto f32 = [&]( float v ) { return __uint_as_float(u32(__float_as_uint(v))); };
+		    base = u32((uint32_t)( st.base - origin ));
+		    rp = base + u32((uint32_t)( st.rp - st.base ));
+		    advance = u32(st.advance);
+		    carrier = ( u32(st.flags) & MIFSK_STATE_CARRIER ) != 0u;
+		    carrier_nsamples = ( (uint64_t)u32((uint32_t)( st.carrier_nsamples >> 32 )) << 32 )
+				     | u32((uint32_t)st.carrier_nsamples);
+		    confidence_total = f32(st.confidence_total);
+		    amplitude_total = f32(st.amplitude_total);
+		    nframes_decoded = u32(st.nframes_decoded);
+		    noconfidence = u32(st.noconfidence);
+		    track_amplitude = f32(st.track_amplitude);
+		    peak_confidence = f32(st.peak_confidence);
+		    ep_first = u32(st.ep_first);
+		    ep_b_mark = u32(st.ep_b_mark);
+		    frame_base = u32((uint32_t)st.nframes_total);
+		    if ( rs.append ) {
+			// the outputs continue where the call before stopped instead of at index 0
+			n_out_frames = frame_base;
+			n_out_bytes = u32(st.nbytes_total);
+			n_out_eps = u32(st.nepisodes_total);
+			status = u32(st.status);
+			frame_base = 0u;
+		    }
+		}
+	    }
+	}
+    }
+    // With more of the stream to come, a pass of the loop is run only when a whole
+    // samplebuf beyond its cursor is in the row: then every refill is a full half buffer
+    // and every sample a search can read is the stream's, exactly as in a single call.
+    // Lattice frames are accepted up to that horizon (N_lat), the general path stops at it.
+    const uint32_t bufsize = ST ? rs.bufsize : 0u, half = bufsize / 2u;
+    const uint32_t N_lat = last_slab ? N : ( N > bufsize ? N - bufsize : 0u );
+    bool paused = false;
 
     uint32_t cyc_bulk = 0, cyc_general = 0, cyc_restart = 0, cyc_s1 = 0, cyc_s2 = 0, cyc_dpp = 0;
     const uint32_t t_start = MIFSK_CLOCK();
@@ -761,6 +850,8 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
     const ZigZag zc0(cfg, 0u), zc1(cfg, 1u), zf0(cfg, 2u), zf1(cfg, 3u);
 
     for (;;) {
+	if ( ST && !resumable )
+	    break;
 	// ------------------------------------------------------------------
 	// Bulk acceptance of lattice frames.  While carrier is held and the
 	// cursor lands on the lattice, the reference's iteration for frame k
@@ -770,7 +861,7 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 	// order from the scored (confidence, amplitude) pairs; the first frame
 	// that fails any of them falls through to the general path below.
 	// ------------------------------------------------------------------
-	if ( carrier && advance && advance <= N - base ) {
+	if ( carrier && advance && ( ST ? ( base <= N_lat && advance <= N_lat - base ) : advance <= N - base ) ) {
 	    const uint32_t t_bulk = MIFSK_CLOCK();
 	    const uint32_t first = cfg.try_first[1];
 	    const uint32_t nb = base + advance;		// cursor of the next iteration
@@ -782,8 +873,8 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 		// frame k sits at cursor nb + k*lock_advance and needs expect_nsamples from there
 		const uint32_t fn = cfg.frame_nsamples;
 		const uint32_t la = cfg.lock_advance;
-		const uint32_t room = N - nb >= cfg.expect_nsamples
-				    ? udiv_magic(N - nb - cfg.expect_nsamples, la, cfg.la_magic) + 1u : 0u;
+		const uint32_t room = N_lat - nb >= cfg.expect_nsamples
+				    ? udiv_magic(N_lat - nb - cfg.expect_nsamples, la, cfg.la_magic) + 1u : 0u;
 		K = K < room ? K : room;
 		// this lane's candidate (lane k <-> entry e0 + k)
 		const bool have = lane < K;
@@ -864,7 +955,7 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 			    if ( o.frames ) {
 				mifsk_frame f;
 				f.bits = db;
-				f.start = (uint64_t)nb + (uint64_t)lane * la + first;
+				f.start = origin + (uint64_t)nb + (uint64_t)lane * la + first;
 				f.confidence = cv;
 				f.amplitude = av;
 				f.flags = suppressed ? MIFSK_FRAME_SYNC : 0u;
@@ -893,6 +984,19 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 		    carrier_nsamples += (uint64_t)n * ( fn + first - cfg.overscan );
 		    base = nb + ( n - 1u ) * la;
 		    advance = la;
+		    if constexpr ( ST ) {
+			// (one refill per iteration whenever fewer than half a buffer is valid:
+			// after n iterations the file position is the first rp + m * half that
+			// leaves at least half a buffer beyond the cursor)
+			// -- in closed form (a loop here leaves hipcc with a loop-carried
+			// value it will not keep in a scalar register)
+			if ( rp < base + half && rp < N ) {
+			    const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane(
+				(int)( ( base + half - rp + half - 1u ) / half ));
+			    const uint64_t r2 = (uint64_t)rp + (uint64_t)m * half;
+			    rp = r2 > (uint64_t)N ? N : (uint32_t)r2;
+			}
+		    }
 		    ctx.bump(MIFSK_CNT_BULK_FRAMES, n);
 		    progressed = true;
 		}
@@ -906,16 +1010,43 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 		continue;
 	}
 
-	// minimodem.c:1150-1156,1176,1229 under flat addressing
-	if ( advance ) {
-	    if ( advance > N - base )
+	if constexpr ( ST ) {
+	    // the reference's buffer arithmetic in full (the state carries the file position):
+	    // minimodem.c:1146-1176,1229, statement for statement what the wavefront engine runs
+	    if ( !last_slab && (uint64_t)base + advance + bufsize > (uint64_t)N ) {
+		paused = true;			// it could read beyond the row: the next slab resumes here
 		break;
-	    base += advance;
-	    advance = 0;
+	    }
+	    if ( advance == bufsize ) {		// :1146-1149: samples_nvalid = 0
+		base += advance;
+		rp = base;
+		advance = 0;
+	    }
+	    if ( base > rp )
+		break;
+	    if ( advance ) {			// :1150-1156
+		if ( advance > rp - base )
+		    break;
+		base += advance;
+		advance = 0;
+	    }
+	    if ( rp - base < half )		// :1158-1174
+		rp += N - rp < half ? N - rp : half;
+	    const uint32_t nvalid = rp - base;
+	    if ( nvalid == 0 || nvalid < cfg.expect_nsamples )	// :1176,1229
+		break;
+	} else {
+	    // minimodem.c:1150-1156,1176,1229 under flat addressing
+	    if ( advance ) {
+		if ( advance > N - base )
+		    break;
+		base += advance;
+		advance = 0;
+	    }
+	    const uint32_t avail = N - base;
+	    if ( avail == 0 || avail < cfg.expect_nsamples )
+		break;
 	}
-	const uint32_t avail = N - base;
-	if ( avail == 0 || avail < cfg.expect_nsamples )
-	    break;
 	ctx.bump(MIFSK_CNT_ITERATIONS);
 	const uint32_t t_gen = MIFSK_CLOCK();
 
@@ -980,7 +1111,8 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 	    carrier = true;					// minimodem.c:1350-1353
 	    refine = true;
 	    flags |= MIFSK_FRAME_ACQUIRE;
-	    ep_first = n_out_frames;
+	    ep_first = frame_base + n_out_frames;
+	    ep_b_mark = cfg.b_mark;
 	}
 
 	if ( refine && confidence < INFINITY && try_step > 1u ) {	// minimodem.c:1357-1389
@@ -1028,7 +1160,7 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 		if ( o.frames ) {
 		    mifsk_frame f;
 		    f.bits = bits;
-		    f.start = (uint64_t)base + frame_start;
+		    f.start = origin + (uint64_t)base + frame_start;
 		    f.confidence = confidence;
 		    f.amplitude = amplitude;
 		    f.flags = flags;
@@ -1067,7 +1199,40 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
     }
 
 
-    if ( carrier ) {						// minimodem.c:1469-1474
+    if constexpr ( ST ) {
+	if ( stateful && t0 && !( status & MIFSK_STREAM_ABORTED ) && resumable ) {
+	    mifsk_stream_state st;
+	    st.base = origin + base;
+	    st.rp = origin + rp;
+	    st.carrier_nsamples = carrier_nsamples;
+	    st.nframes_total = (uint64_t)frame_base + n_out_frames;
+	    st.advance = advance;
+	    st.flags = MIFSK_STATE_STARTED | ( carrier ? MIFSK_STATE_CARRIER : 0u )
+		     | ( paused ? 0u : MIFSK_STATE_FINISHED );
+	    st.confidence_total = confidence_total;
+	    st.amplitude_total = amplitude_total;
+	    st.nframes_decoded = nframes_decoded;
+	    st.noconfidence = noconfidence;
+	    st.track_amplitude = track_amplitude;
+	    st.peak_confidence = peak_confidence;
+	    st.carrier_band = -1;			// (--auto-carrier runs on the wavefront engine)
+	    st.first_band = -1;
+	    st.b_mark = cfg.b_mark;
+	    st.ep_b_mark = ep_b_mark;
+	    st.ep_first = ep_first;
+	    const uint32_t b0 = rs.append ? 0u : rs.d_state[s].nbytes_total, e0 = rs.append ? 0u : rs.d_state[s].nepisodes_total;
+	    st.nbytes_total = b0 + n_out_bytes;
+	    st.nepisodes_total = e0 + n_out_eps;
+	    st.status = rs.d_state[s].status | status;
+	    rs.d_state[s] = st;
+	} else if ( stateful && t0 && ( status & MIFSK_STREAM_ABORTED ) ) {
+	    mifsk_stream_state st = rs.d_state[s];
+	    st.flags |= MIFSK_STATE_STARTED | MIFSK_STATE_FINISHED;
+	    st.status |= MIFSK_STREAM_ABORTED;
+	    rs.d_state[s] = st;
+	}
+    }
+    if ( carrier && !( ST && ( paused || !resumable ) ) ) {	// minimodem.c:1469-1474
 	if ( t0 && o.eps && n_out_eps < o.ecap ) {
 	    mifsk_episode e;
 	    e.carrier_nsamples = carrier_nsamples;
@@ -1081,7 +1246,8 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 	}
 	n_out_eps++;
     }
-    if ( t0 ) {
+    // (append: a stream the call before finished keeps the outputs that call wrote)
+    if ( t0 && !( ST && rs.append != 0u && !resumable && status == 0u ) ) {
 	if ( n_out_frames > o.fcap && ( o.bits || o.frames || o.bytes ) )
 	    status |= MIFSK_STREAM_FRAMES_TRUNCATED;
 	if ( n_out_eps > o.ecap && o.eps )
@@ -1113,8 +1279,9 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 	    c[22] = (uint64_t)( __builtin_amdgcn_s_getreg(( 3 << 11 ) | 20) & 15 ) << 32;
 #endif
 	}
-	ctx.next_cmd()->op = CMD_EXIT;
     }
+    if ( t0 )
+	ctx.next_cmd()->op = CMD_EXIT;		// (whatever was or was not written above)
     lds_barrier();				// releases the workers with "exit"
 }
 
@@ -1409,11 +1576,11 @@ __device__ __forceinline__ void worker_main( const DevCfg *__restrict__ cfgp,
 #endif
 }
 
-template <bool USE_SLAB, int NQ, int NW>
+template <bool USE_SLAB, int NQ, int NW, bool ST = false>
 __global__ __launch_bounds__(64 * ( NW + 1 ), 3)
 void demod_kernel( const DevCfg *__restrict__ cfgp, const double *__restrict__ tw,
 	mifsk_demod_io io, uint32_t slab_cap, uint32_t lat_frames, uint32_t lat_rounds,
-	uint32_t region_floats, uint32_t region_cap, uint32_t lat_mode )
+	uint32_t region_floats, uint32_t region_cap, uint32_t lat_mode, WgResume rs )
 {
     StreamLds *lds = reinterpret_cast<StreamLds *>(mifsk_smem);
     const uint32_t base0 = 0u;
@@ -1435,8 +1602,14 @@ void demod_kernel( const DevCfg *__restrict__ cfgp, const double *__restrict__ t
     uint32_t n_own = io.d_nsamples ? io.d_nsamples[blockIdx.x] : io.nsamples;
     if ( io.nstreams > 1 && (size_t)n_own > io.stream_stride )
 	n_own = (uint32_t)io.stream_stride;
+    const uint32_t n_row = n_own;
+    if constexpr ( ST ) {
+	// a chained launch sees the first rs.limit samples of a row, master and workers alike
+	if ( rs.d_state && rs.limit != 0u && rs.limit < n_own )
+	    n_own = rs.limit;
+    }
     const uint64_t rows_after = (uint64_t)( io.nstreams - 1 - (int)blockIdx.x ) * io.stream_stride;
-    const uint32_t safe_limit = rows_after == 0 ? n_own
+    const uint32_t safe_limit = rows_after == 0 ? n_row
 			      : rows_after > 0xFFFF0000ull ? 0xFFFF0000u : (uint32_t)rows_after;
     if ( lat_mode == LAT_LINEAR && safe_limit < 64u * STAGE_VEC * 4u )
 	lat_frames = 0;
@@ -1445,7 +1618,7 @@ void demod_kernel( const DevCfg *__restrict__ cfgp, const double *__restrict__ t
 	// the serial chain is the critical path of the workgroup: let it win
 	// issue arbitration against the (throughput-bound) worker waves
 	__builtin_amdgcn_s_setprio(3);
-	master_loop<USE_SLAB, NQ>(cfg, tw, io, slab_cap, lat_frames * lat_rounds, lat_frames, lat_mode, base0, lds);
+	master_loop<USE_SLAB, NQ, ST>(cfg, tw, io, slab_cap, lat_frames * lat_rounds, lat_frames, lat_mode, base0, lds, rs);
     } else {
 	worker_main<USE_SLAB, NQ>(cfgp, tw, lds, io.d_samples + (size_t)blockIdx.x * io.stream_stride,
 			      n_own, slab_cap, lat_frames, region_floats, region_cap, lat_mode, safe_limit,
@@ -1508,7 +1681,8 @@ static constexpr size_t kLdsPerCu = 160 * 1024;
 static constexpr int kNotBell202 = -100000;
 
 static int launch_with_workers( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_tw,
-	const mifsk_demod_io &io, void *stream, LaunchInfo *plan_only, const uint32_t nworkers )
+	const mifsk_demod_io &io, void *stream, LaunchInfo *plan_only, const uint32_t nworkers,
+	const WgHostArgs *wh )
 {
     const uint32_t B = cfg.bit_nsamples;
     const uint32_t lat_lanes = nworkers * 64u;	// bit windows per lattice round
@@ -1613,15 +1787,132 @@ static int launch_with_workers( const DevCfg &cfg, const DevCfg *d_cfg, const do
     const bool bell202 = nworkers == 2u && use_slab && lat_mode == LAT_LINEAR && B == 40u;
     if ( nworkers == 2u && !bell202 )
 	return kNotBell202;
+    const size_t lds_all = use_slab ? kLdsHeader + slab_floats * 4 : kLdsHeader + 16;
+    // Chained launches (as in launch_demod_wave): a batch of more streams than
+    // the chip holds at once is cut into G groups of streams x K time chunks, each (group,
+    // chunk) its own grid of the RESUMABLE instantiation on the group's stream.  A chunk of this
+    // engine restarts with a search and a pipeline fill (~10 us per stream), so chunks are long:
+    // at least 32 samplebufs, at most four per stream.
+    uint32_t chain_g = 0, chain_k = 0;
+    if ( wh ) {
+	const uint32_t by_lds = (uint32_t)( kLdsPerCu / lds_all );
+	const uint32_t by_regs = 12u / ( nworkers + 1u );	// three waves per SIMD
+	const uint64_t slots = (uint64_t)( by_lds < by_regs ? by_lds : by_regs ) * (uint64_t)( wh->ncu > 0 ? wh->ncu : 1 );
+	const bool allowed = ( plan_only ? wh->chain_ok : wh->chain != nullptr ) && !wh->d_state
+			  && !io.d_counters && io.nstreams > 0;
+	if ( allowed && (uint64_t)io.nstreams > slots && wh->samplebuf_size > 0u ) {
+	    chain_g = 2u;
+	    chain_k = io.nsamples / ( 32u * wh->samplebuf_size );
+	    if ( chain_k > 4u ) chain_k = 4u;
+	}
+	if ( const char *e = experiment_env("MIFSK_CHAIN") ) {	// experiments and tests only: "G,K", any batch
+	    int a = 0, b = 0;
+	    if ( allowed && std::sscanf(e, "%d,%d", &a, &b) == 2 ) {
+		chain_g = (uint32_t)( a < 0 ? 0 : a );
+		chain_k = (uint32_t)( b < 0 ? 0 : b );
+	    }
+	}
+	if ( chain_g > (uint32_t)WaveChain::kMaxGroups ) chain_g = (uint32_t)WaveChain::kMaxGroups;
+	if ( chain_g > (uint32_t)io.nstreams ) chain_g = (uint32_t)io.nstreams;
+	if ( chain_g < 1u || chain_k < 2u )
+	    chain_g = chain_k = 0u;
+    }
+    const bool resumable = ( wh && wh->d_state ) || chain_g;
     if ( plan_only ) {
-	plan_only->kernel = !use_slab ? "mifsk::demod_kernel<false, 0, 3>"
-			  : bell202 ? "mifsk::demod_kernel<true, 10, 2>" : "mifsk::demod_kernel<true, 0, 3>";
+	plan_only->kernel = !use_slab ? ( resumable ? "mifsk::demod_kernel<false, 0, 3, true>" : "mifsk::demod_kernel<false, 0, 3>" )
+			  : bell202 ? ( resumable ? "mifsk::demod_kernel<true, 10, 2, true>" : "mifsk::demod_kernel<true, 10, 2>" )
+				    : ( resumable ? "mifsk::demod_kernel<true, 0, 3, true>" : "mifsk::demod_kernel<true, 0, 3>" );
 	plan_only->workgroup_size = block;
-	plan_only->lds_bytes = (uint32_t)( use_slab ? kLdsHeader + slab_floats * 4 : kLdsHeader + 16 );
+	plan_only->lds_bytes = (uint32_t)lds_all;
 	plan_only->lattice_mode = lat_mode;
 	plan_only->frames_per_block = lat_frames * lat_rounds;
 	plan_only->waves_per_simd = bell202 ? 3 : 4;
+	plan_only->chain_groups = chain_g;
+	plan_only->chain_chunks = chain_k;
 	return 0;
+    }
+    WgResume rs;
+    std::memset(&rs, 0, sizeof(rs));
+    if ( resumable ) {
+	// mifsk_demod_slab and the chained launches: the instantiations with the state code
+	rs.d_state = wh->d_state;
+	rs.d_origin = wh->d_origin;
+	rs.final = wh->final ? 1u : 0u;
+	rs.bufsize = wh->samplebuf_size;
+	const void *fn = !use_slab ? reinterpret_cast<const void *>(&demod_kernel<false, 0, 3, true>)
+		       : bell202 ? reinterpret_cast<const void *>(&demod_kernel<true, 10, 2, true>)
+				 : reinterpret_cast<const void *>(&demod_kernel<true, 0, 3, true>);
+	if ( hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_all) != hipSuccess )
+	    return -5;
+	uint32_t a_slab_cap = use_slab ? slab_cap : 0u, a_lat_frames = use_slab ? lat_frames : 0u;
+	uint32_t a_lat_rounds = use_slab ? lat_rounds : 1u, a_region_floats = use_slab ? (uint32_t)region_floats : 0u;
+	uint32_t a_region_cap = use_slab ? region_cap : 0u, a_lat_mode = use_slab ? lat_mode : (uint32_t)LAT_NONE;
+	if ( !chain_g ) {
+	    mifsk_demod_io o = io;
+	    void *kargs[] = { (void *)&d_cfg, (void *)&d_tw, (void *)&o, (void *)&a_slab_cap, (void *)&a_lat_frames,
+			      (void *)&a_lat_rounds, (void *)&a_region_floats, (void *)&a_region_cap, (void *)&a_lat_mode, (void *)&rs };
+	    (void)hipLaunchKernel(fn, dim3((unsigned)io.nstreams), dim3(block), kargs, lds_all, st);
+	    return hip_rc(hipGetLastError());
+	}
+	const WaveChain &ch = *wh->chain;
+	if ( (size_t)io.nstreams > ch.state_cap )
+	    return -12;
+	hipEvent_t fork = (hipEvent_t)ch.ev_fork;
+	if ( hipEventRecord(fork, st) != hipSuccess )
+	    return -5;
+	mifsk_demod_io gio[WaveChain::kMaxGroups];
+	uint32_t glo[WaveChain::kMaxGroups];
+	for ( uint32_t gi = 0; gi < chain_g; gi++ ) {
+	    hipStream_t gs = (hipStream_t)ch.streams[gi];
+	    // behind the caller's stream, and behind whatever the call before left on ANY group's
+	    // stream (its groups were other ranges of the state array)
+	    (void)hipStreamWaitEvent(gs, fork, 0);
+	    for ( uint32_t h = 0; h < (uint32_t)WaveChain::kMaxGroups; h++ )
+		if ( h != gi )
+		    (void)hipStreamWaitEvent(gs, (hipEvent_t)ch.ev_done[h], 0);
+	    const uint32_t lo = (uint32_t)( (uint64_t)io.nstreams * gi / chain_g );
+	    const uint32_t hi = (uint32_t)( (uint64_t)io.nstreams * ( gi + 1u ) / chain_g );
+	    glo[gi] = lo;
+	    mifsk_demod_io &o = gio[gi];
+	    o = io;
+	    o.nstreams = (int)( hi - lo );
+	    o.d_samples = io.d_samples + (size_t)lo * io.stream_stride;
+	    if ( io.d_nsamples ) o.d_nsamples = io.d_nsamples + lo;
+	    if ( io.d_bytes ) o.d_bytes = io.d_bytes + (size_t)lo * io.frames_cap;
+	    if ( io.d_nbytes ) o.d_nbytes = io.d_nbytes + lo;
+	    if ( io.d_bits ) o.d_bits = io.d_bits + (size_t)lo * io.frames_cap;
+	    if ( io.d_frames ) o.d_frames = io.d_frames + (size_t)lo * io.frames_cap;
+	    if ( io.d_nframes ) o.d_nframes = io.d_nframes + lo;
+	    if ( io.d_episodes ) o.d_episodes = io.d_episodes + (size_t)lo * io.episodes_cap;
+	    if ( io.d_nepisodes ) o.d_nepisodes = io.d_nepisodes + lo;
+	    if ( io.d_status ) o.d_status = io.d_status + lo;
+	    if ( o.nstreams > 0
+		    && hipMemsetAsync(ch.d_state + lo, 0, (size_t)o.nstreams * sizeof(mifsk_stream_state), gs) != hipSuccess )
+		return -5;
+	}
+	const uint32_t chunk = ( io.nsamples + chain_k - 1u ) / chain_k;
+	rs.append = 1u;
+	rs.d_origin = nullptr;
+	for ( uint32_t k = 0; k < chain_k; k++ ) {
+	    const bool last = k + 1u == chain_k;
+	    rs.final = last ? 1u : 0u;
+	    rs.limit = last ? 0u : ( k + 1u ) * chunk;
+	    for ( uint32_t gi = 0; gi < chain_g; gi++ ) {
+		if ( gio[gi].nstreams <= 0 )
+		    continue;
+		rs.d_state = ch.d_state + glo[gi];
+		void *kargs[] = { (void *)&d_cfg, (void *)&d_tw, (void *)&gio[gi], (void *)&a_slab_cap, (void *)&a_lat_frames,
+				  (void *)&a_lat_rounds, (void *)&a_region_floats, (void *)&a_region_cap, (void *)&a_lat_mode, (void *)&rs };
+		(void)hipLaunchKernel(fn, dim3((unsigned)gio[gi].nstreams), dim3(block), kargs, lds_all,
+				      (hipStream_t)ch.streams[gi]);
+	    }
+	}
+	const bool launched = hipGetLastError() == hipSuccess;
+	for ( uint32_t gi = 0; gi < chain_g; gi++ ) {
+	    (void)hipEventRecord((hipEvent_t)ch.ev_done[gi], (hipStream_t)ch.streams[gi]);
+	    (void)hipStreamWaitEvent(st, (hipEvent_t)ch.ev_done[gi], 0);
+	}
+	return launched ? 0 : -5;
     }
     if ( use_slab ) {
 	const size_t lds_bytes = kLdsHeader + slab_floats * 4;
@@ -1634,29 +1925,29 @@ static int launch_with_workers( const DevCfg &cfg, const DevCfg *d_cfg, const do
 	if ( bell202 )
 	    hipLaunchKernelGGL((demod_kernel<true, 10, 2>), dim3((unsigned)io.nstreams), dim3(block),
 			       lds_bytes, st, d_cfg, d_tw, io, slab_cap, lat_frames, lat_rounds,
-			       (uint32_t)region_floats, region_cap, lat_mode);
+			       (uint32_t)region_floats, region_cap, lat_mode, rs);
 	else
 	    hipLaunchKernelGGL((demod_kernel<true, 0, 3>), dim3((unsigned)io.nstreams), dim3(block),
 			       lds_bytes, st, d_cfg, d_tw, io, slab_cap, lat_frames, lat_rounds,
-			       (uint32_t)region_floats, region_cap, lat_mode);
+			       (uint32_t)region_floats, region_cap, lat_mode, rs);
     } else {
 	hipLaunchKernelGGL((demod_kernel<false, 0, 3>), dim3((unsigned)io.nstreams), dim3(block),
-			   kLdsHeader + 16, st, d_cfg, d_tw, io, 0u, 0u, 1u, 0u, 0u, (uint32_t)LAT_NONE);
+			   kLdsHeader + 16, st, d_cfg, d_tw, io, 0u, 0u, 1u, 0u, 0u, (uint32_t)LAT_NONE, rs);
     }
     return hip_rc(hipGetLastError());
 }
 
 int launch_demod_batch( const DevCfg &cfg, const DevCfg *d_cfg, const double *d_tw,
-	const mifsk_demod_io &io, void *stream, LaunchInfo *plan_only )
+	const mifsk_demod_io &io, void *stream, LaunchInfo *plan_only, const WgHostArgs *wh )
 {
     if ( io.nstreams <= 0 && !plan_only )
 	return 0;
     if ( cfg.lat_linear && cfg.bit_nsamples == 40u ) {
-	const int rc = launch_with_workers(cfg, d_cfg, d_tw, io, stream, plan_only, 2u);
+	const int rc = launch_with_workers(cfg, d_cfg, d_tw, io, stream, plan_only, 2u, wh);
 	if ( rc != kNotBell202 )
 	    return rc;
     }
-    return launch_with_workers(cfg, d_cfg, d_tw, io, stream, plan_only, 3u);
+    return launch_with_workers(cfg, d_cfg, d_tw, io, stream, plan_only, 3u, wh);
 }
 
 int launch_detect_carrier( const float *d_samples, unsigned nsamples,

@@ -25,40 +25,49 @@ def gpu():
     ctx.close()
 
 
-def _chained(M, ctx, cfg, n, nsamples):
-    p = M.demod_plan(ctx, cfg, n, engine="wave", nsamples=nsamples)
+def _chained(M, ctx, cfg, n, nsamples, engine="wave"):
+    p = M.demod_plan(ctx, cfg, n, engine=engine, nsamples=nsamples)
     return p["chain_groups"], p["chain_chunks"]
 
 
+@pytest.mark.parametrize("engine", ["wave", "workgroup"])
 @pytest.mark.parametrize("cut", CUTS)
 @pytest.mark.parametrize("name", G.names())
-def test_chained_launches_give_the_oracles_streams_on_goldens(gpu, monkeypatch, name, cut):
+def test_chained_launches_give_the_oracles_streams_on_goldens(gpu, monkeypatch, name, cut, engine):
     M, torch, ctx = gpu
     g = G.load(name)
     cfg = M.rx_config(**g["cfg_kwargs"])
     x = g["samples"]
     if len(x) > 2_000_000:
         pytest.skip("one long stream: covered by the slab tests")
+    if engine == "workgroup" and cfg.auto_carrier_threshold > 0:
+        pytest.skip("--auto-carrier runs on the wavefront engine")
     streams = [x, x[:int(len(x) * 0.61)], x[int(len(x) * 0.13):], x]
     monkeypatch.setenv("MIFSK_EXPERIMENT", "1")
     monkeypatch.setenv("MIFSK_CHAIN", cut)
-    groups, chunks = _chained(M, ctx, cfg, len(streams), (len(x) + 3) & ~3)
+    groups, chunks = _chained(M, ctx, cfg, len(streams), (len(x) + 3) & ~3, engine)
     if not groups:
-        # only where the mode's kernel instantiation has no resumable twin (its batches are never cut)
+        # only where the mode's kernel instantiation has no resumable twin (its batches are never
+        # cut): the wavefront engine's fixed-length ones; every workgroup instantiation has one
+        assert engine == "wave"
         monkeypatch.setenv("MIFSK_CHAIN", "0,0")
         plain = M.demod_plan(ctx, cfg, len(streams), engine="wave", nsamples=(len(x) + 3) & ~3)["kernel"]
         assert any(t in plain for t in ("<10, 10>", "<10, 5>", "<4, 1>")), plain
         pytest.skip("no resumable twin of " + plain)
     assert (groups, chunks) == tuple(int(v) for v in cut.split(","))
-    res = run_gpu_streams(M, torch, ctx, cfg, streams, engine="wave")
+    assert ", true>" in M.demod_plan(ctx, cfg, len(streams), engine=engine, nsamples=(len(x) + 3) & ~3)["kernel"]
+    res = run_gpu_streams(M, torch, ctx, cfg, streams, engine=engine)
     ocfg = O.oracle_config(**g["cfg_kwargs"])
     for i, s in enumerate(streams):
         assert_stream_equal(res, i, O.oracle_rx_stream(ocfg, s), "%s cut %s" % (name, cut))
 
 
-@pytest.mark.parametrize("mode,opts", [("rtty", {}), ("300", {}), ("same", {}), ("110", {})])
-def test_chained_equals_single_launch_on_noisy_ragged_batch(gpu, monkeypatch, mode, opts):
+@pytest.mark.parametrize("engine", ["wave", "workgroup"])
+@pytest.mark.parametrize("mode,opts", [("rtty", {}), ("300", {}), ("same", {}), ("110", {}), ("1200", {}), ("2400", {})])
+def test_chained_equals_single_launch_on_noisy_ragged_batch(gpu, monkeypatch, mode, opts, engine):
     M, torch, ctx = gpu
+    if engine == "workgroup" and mode in ("rtty", "same"):
+        pytest.skip("covered on the wavefront engine (the workgroup engine's direct lattice is slow here)")
     cfg = M.rx_config(mode, **opts)
     ocfg = O.oracle_config(mode, **opts)
     rng = np.random.default_rng(77)
@@ -73,13 +82,13 @@ def test_chained_equals_single_launch_on_noisy_ragged_batch(gpu, monkeypatch, mo
         streams.append(x.astype(np.float32))
     monkeypatch.setenv("MIFSK_EXPERIMENT", "1")
     monkeypatch.setenv("MIFSK_CHAIN", "0,0")
-    single = run_gpu_streams(M, torch, ctx, cfg, streams, engine="wave")
+    single = run_gpu_streams(M, torch, ctx, cfg, streams, engine=engine)
     stride = (max(len(s) for s in streams) + 3) & ~3
     for cut in ("2,4", "3,9"):
         monkeypatch.setenv("MIFSK_CHAIN", cut)
-        if not _chained(M, ctx, cfg, len(streams), stride)[0]:
+        if not _chained(M, ctx, cfg, len(streams), stride, engine)[0]:
             pytest.skip("no resumable twin for this mode's instantiation")
-        res = run_gpu_streams(M, torch, ctx, cfg, streams, engine="wave")
+        res = run_gpu_streams(M, torch, ctx, cfg, streams, engine=engine)
         for key in ("nframes", "nbytes", "nepisodes", "status"):
             assert np.array_equal(res[key], single[key]), (mode, cut, key)
         for i in range(len(streams)):

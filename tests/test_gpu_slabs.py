@@ -2,7 +2,9 @@
 refills of src/minimodem.c:1144-1174 -- its loop never sees more than one samplebuf at a time).
 Any cut of a stream into slabs must give the frames, bytes and episodes of the single call --
 and of the oracle -- bit for bit: the loop's state (cursor, buffer arithmetic, carrier totals,
-tracker, --auto-carrier band) is carried in device memory from call to call."""
+tracker, --auto-carrier band) is carried in device memory from call to call.  Both engines
+(the wavefront kernel's and the workgroup kernel's resumable instantiations) and the two taking
+turns on one stream: the state record is common to them."""
 import numpy as np
 import pytest
 
@@ -21,18 +23,23 @@ def gpu():
     ctx.close()
 
 
-def _feed_in_slabs(M, ctx, cfg, streams, cuts_per_stream, episodes_cap=32):
+def _feed_in_slabs(M, ctx, cfg, streams, cuts_per_stream, episodes_cap=32, engine=None):
     """cuts_per_stream[i] = sorted cut positions of stream i (same count for all streams).
-    Returns per-stream dict(frames, bytes, episodes) concatenated over the calls."""
+    Returns per-stream dict(frames, bytes, episodes) concatenated over the calls.
+    engine: "wave", "workgroup", None (the library's choice) or "alternate" (the engines take
+    turns from slab to slab: one state record serves both)."""
     n = len(streams)
     ncalls = len(cuts_per_stream[0]) + 1
-    sess = M.SlabSession(ctx, cfg, n, episodes_cap=episodes_cap)
+    sess = M.SlabSession(ctx, cfg, n, episodes_cap=episodes_cap,
+                         engine=None if engine == "alternate" else engine)
     acc = [dict(frames=[], bytes=b"", episodes=[], bits=[]) for _ in range(n)]
     for k in range(ncalls):
         new = []
         for i, x in enumerate(streams):
             edges = [0] + list(cuts_per_stream[i]) + [len(x)]
             new.append(x[edges[k]:edges[k + 1]])
+        if engine == "alternate":
+            sess.engine = ("workgroup", "wave")[k & 1]
         res = sess.feed(new, final=(k == ncalls - 1))
         for i in range(n):
             assert int(res["status"][i]) == 0
@@ -48,8 +55,9 @@ def _feed_in_slabs(M, ctx, cfg, streams, cuts_per_stream, episodes_cap=32):
     return acc
 
 
+@pytest.mark.parametrize("engine", ["wave", "workgroup", "alternate"])
 @pytest.mark.parametrize("name", G.names())
-def test_any_golden_fed_in_three_slabs_equals_one_shot_and_oracle(gpu, name):
+def test_any_golden_fed_in_three_slabs_equals_one_shot_and_oracle(gpu, name, engine):
     M, torch, ctx = gpu
     g = G.load(name)
     cfg = M.rx_config(**g["cfg_kwargs"])
@@ -57,13 +65,15 @@ def test_any_golden_fed_in_three_slabs_equals_one_shot_and_oracle(gpu, name):
     x = g["samples"]
     if len(x) > 2000000:
         pytest.skip("0.5 baud: one samplebuf is longer than the recording's slabs")
+    if engine != "wave" and cfg.auto_carrier_threshold > 0:
+        pytest.skip("--auto-carrier runs on the wavefront engine")
     rng = np.random.default_rng(len(x))
     ref = O.oracle_rx_stream(ocfg, x)
     for trial in range(3):
         cuts = sorted(int(c) for c in rng.integers(0, len(x) + 1, size=3))
         if trial == 2:
             cuts = [1, 2, len(x) // 2]                    # slabs far shorter than a samplebuf
-        got = _feed_in_slabs(M, ctx, cfg, [x], [cuts])[0]
+        got = _feed_in_slabs(M, ctx, cfg, [x], [cuts], engine=engine)[0]
         assert got["frames"].tobytes() == ref["frames"].tobytes(), (name, cuts)
         assert got["bytes"] == ref["bytes"], (name, cuts)
         assert got["episodes"].tobytes() == ref["episodes"].tobytes(), (name, cuts)
@@ -72,11 +82,14 @@ def test_any_golden_fed_in_three_slabs_equals_one_shot_and_oracle(gpu, name):
 @pytest.mark.parametrize("mode,kw", [("1200", {}), ("300", {}), ("12000", {}), ("same", {}), ("rtty", {}),
                                      ("1200", dict(auto_carrier_threshold=0.001)), ("uic-ground", {})],
                          ids=["1200", "300", "12000", "same", "rtty", "1200-auto", "uic"])
-def test_batch_of_streams_fed_in_many_ragged_slabs(gpu, mode, kw):
+@pytest.mark.parametrize("engine", ["wave", "workgroup", "alternate"])
+def test_batch_of_streams_fed_in_many_ragged_slabs(gpu, mode, kw, engine):
     """A batch whose streams are cut at different places, seven slabs each (some empty, some a
     few samples): noisy, with gaps between bursts (episodes that end inside one slab and are
     reported by a later call), ragged lengths."""
     M, torch, ctx = gpu
+    if engine != "wave" and kw:
+        pytest.skip("--auto-carrier runs on the wavefront engine")
     cfg = M.rx_config(mode, **kw)
     ocfg = O.oracle_config(mode, **kw)
     rng = np.random.default_rng(808)
@@ -105,7 +118,7 @@ def test_batch_of_streams_fed_in_many_ragged_slabs(gpu, mode, kw):
     for x in streams:
         c = sorted(int(v) for v in rng.integers(0, len(x) + 1, size=6))
         cuts.append(c)
-    got = _feed_in_slabs(M, ctx, cfg, streams, cuts)
+    got = _feed_in_slabs(M, ctx, cfg, streams, cuts, engine=engine)
     total = 0
     for i, x in enumerate(streams):
         ref = O.oracle_rx_stream(ocfg, x)
@@ -116,7 +129,8 @@ def test_batch_of_streams_fed_in_many_ragged_slabs(gpu, mode, kw):
     assert total > 100
 
 
-def test_stream_longer_than_one_call_keeps_only_a_samplebuf_of_history(gpu):
+@pytest.mark.parametrize("engine", ["wave", "workgroup"])
+def test_stream_longer_than_one_call_keeps_only_a_samplebuf_of_history(gpu, engine):
     """What the state is for: a long stream fed 50 000 samples at a time.  After every call the
     caller may drop everything before state.base -- never more than a samplebuf plus one frame
     behind the newest sample."""
@@ -126,7 +140,7 @@ def test_stream_longer_than_one_call_keeps_only_a_samplebuf_of_history(gpu):
     rng = np.random.default_rng(4)
     x = M.synthesize(cfg, rng.integers(32, 127, size=2000, dtype=np.uint8), leading_silence=777)
     x = (x + rng.normal(0, 0.03, x.shape)).astype(np.float32)
-    sess = M.SlabSession(ctx, cfg, 1)
+    sess = M.SlabSession(ctx, cfg, 1, engine=engine)
     frames = []
     fed = 0
     while fed < len(x):
