@@ -427,6 +427,20 @@ typedef struct mifsk_stream_state {
 int mifsk_demod_slab( mifsk_ctx *ctx, const mifsk_rx_config *cfg, const mifsk_demod_io *io,
 	mifsk_stream_state *d_state, const uint64_t *d_origin, int final, void *stream );
 
+/* The same with the reference's buffer semantics (MIFSK_IO_RING_EXACT): what a search
+ * reads behind samples_nvalid is what the reference's samplebuf holds there -- stale
+ * samples that memmove left behind (minimodem.c:1150-1156) -- also across calls.
+ * d_ring is [nstreams][mifsk_ring_floats(cfg)] floats of device memory that the
+ * caller zeroes before a stream's first slab and keeps with d_state; a pass of the
+ * loop needs only the refill the reference's fread would deliver (half a samplebuf)
+ * to be in the row, not a whole samplebuf beyond the cursor.  Any cut gives the
+ * one-shot MIFSK_IO_RING_EXACT result, i.e. `minimodem --rx --file`'s, digit for
+ * digit.  Wavefront engine. */
+size_t mifsk_ring_floats( const mifsk_rx_config *cfg );
+int mifsk_demod_slab_ring( mifsk_ctx *ctx, const mifsk_rx_config *cfg, const mifsk_demod_io *io,
+	mifsk_stream_state *d_state, const uint64_t *d_origin, float *d_ring, int final,
+	void *stream );
+
 /* ---- several GPUs (SURVEY 8 e) -------------------------------------------- */
 
 /* Streams are independent: device k of `world` owns the contiguous, balanced

@@ -744,12 +744,19 @@ class SlabSession:
     memory between calls, the unconsumed tail of every stream on the host.  Whatever the cuts,
     the concatenated output is the single call's, bit for bit."""
 
-    def __init__(self, ctx, cfg, nstreams, episodes_cap=16, engine=None):
+    def __init__(self, ctx, cfg, nstreams, episodes_cap=16, engine=None, ring_exact=False):
         """engine: None (the library chooses, as demod_batch does), "wave" or "workgroup"; may
-        be changed between feeds (self.engine): the state record is the same for both."""
+        be changed between feeds (self.engine): the state record is the same for both.
+        ring_exact: the reference's buffer semantics (mifsk_demod_slab_ring): its samplebuf
+        cells persist in device memory between the feeds."""
         torch = _torch()
         self.ctx, self.cfg, self.n = ctx, cfg, int(nstreams)
         self.engine = engine
+        self.ring = None
+        if ring_exact:
+            nf = int(_lib.load().mifsk_ring_floats(C.byref(cfg)))
+            assert nf > 0
+            self.ring = torch.zeros((self.n, nf), dtype=torch.float32, device="cuda")
         self.episodes_cap = episodes_cap
         self.state = torch.zeros((self.n, STATE_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
         self.origin = np.zeros(self.n, np.uint64)
@@ -802,9 +809,16 @@ class SlabSession:
         io.d_carrier_band = out["carrier_band"].data_ptr()
         io.flags = (_lib.IO_ENGINE_WORKGROUP if self.engine == "workgroup" else 0) | \
             (_lib.IO_ENGINE_WAVE if self.engine == "wave" else 0)
-        rc = lib.mifsk_demod_slab(self.ctx.handle, C.byref(self.cfg), C.byref(io),
-                                  C.c_void_p(self.state.data_ptr()), C.c_void_p(do.data_ptr()),
-                                  1 if final else 0, _stream_ptr(torch, stream))
+        if self.ring is not None:
+            io.flags = _lib.IO_RING_EXACT
+            rc = lib.mifsk_demod_slab_ring(self.ctx.handle, C.byref(self.cfg), C.byref(io),
+                                           C.c_void_p(self.state.data_ptr()), C.c_void_p(do.data_ptr()),
+                                           C.c_void_p(self.ring.data_ptr()), 1 if final else 0,
+                                           _stream_ptr(torch, stream))
+        else:
+            rc = lib.mifsk_demod_slab(self.ctx.handle, C.byref(self.cfg), C.byref(io),
+                                      C.c_void_p(self.state.data_ptr()), C.c_void_p(do.data_ptr()),
+                                      1 if final else 0, _stream_ptr(torch, stream))
         if rc != 0:
             raise RuntimeError("mifsk_demod_slab failed: %d" % rc)
         torch.cuda.synchronize()

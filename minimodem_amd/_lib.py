@@ -213,6 +213,7 @@ EXPORTS = [
     "mifsk_demod_batch_host_ex", "mifsk_host_alloc", "mifsk_host_free", "mifsk_max_episodes",
     "mifsk_demod_files", "mifsk_files_count", "mifsk_files_get", "mifsk_files_stats",
     "mifsk_files_free", "mifsk_demod_slab", "mifsk_scan_plan_get",
+    "mifsk_demod_slab_ring", "mifsk_ring_floats",
 ]
 
 _lib = None
@@ -329,5 +330,10 @@ def load():
     lib.mifsk_demod_slab.restype = C.c_int
     lib.mifsk_demod_slab.argtypes = [C.c_void_p, C.POINTER(RxConfig), C.POINTER(DemodIO), C.c_void_p,
                                      C.c_void_p, C.c_int, C.c_void_p]
+    lib.mifsk_demod_slab_ring.restype = C.c_int
+    lib.mifsk_demod_slab_ring.argtypes = [C.c_void_p, C.POINTER(RxConfig), C.POINTER(DemodIO), C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.mifsk_ring_floats.restype = C.c_size_t
+    lib.mifsk_ring_floats.argtypes = [C.POINTER(RxConfig)]
     _lib = lib
     return lib

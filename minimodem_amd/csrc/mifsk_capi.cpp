@@ -708,7 +708,8 @@ static int chain_prepare( mifsk_ctx *ctx, size_t ns )
 static int demod_batch_wave( mifsk_ctx *ctx, const mifsk_rx_config *cfg, const DevCfg &d,
 	const DevCfg *d_cfg, const double *d_tw, const mifsk_demod_io *io, void *stream,
 	mifsk::LaunchInfo *plan_only = nullptr, mifsk_stream_state *d_state = nullptr,
-	const uint64_t *d_origin = nullptr, bool final = true, const CfgEntry *tables = nullptr )
+	const uint64_t *d_origin = nullptr, bool final = true, const CfgEntry *tables = nullptr,
+	float *d_ring_persistent = nullptr )
 {
     hipStream_t st = (hipStream_t)stream;
     const size_t ns = (size_t)io->nstreams;
@@ -766,12 +767,17 @@ static int demod_batch_wave( mifsk_ctx *ctx, const mifsk_rx_config *cfg, const D
 			   + d.last_reach + 64;
 	ha.ring_exact = true;
 	ha.ring_stride = (uint32_t)( ( (size_t)cfg->samplebuf_size + reach + 3 ) & ~(size_t)3 );
-	if ( hipMallocAsync(&scratch_ring, ns * ha.ring_stride * sizeof(float), st) != hipSuccess
-		|| hipMemsetAsync(scratch_ring, 0, ns * ha.ring_stride * sizeof(float), st) != hipSuccess ) {
-	    if ( scratch_tw ) (void)hipFreeAsync(scratch_tw, st);
-	    return -ENOMEM;
+	if ( d_ring_persistent ) {
+	    // mifsk_demod_slab_ring: the caller's buffer IS the reference's samplebuf between calls
+	    ha.d_ring = d_ring_persistent;
+	} else {
+	    if ( hipMallocAsync(&scratch_ring, ns * ha.ring_stride * sizeof(float), st) != hipSuccess
+		    || hipMemsetAsync(scratch_ring, 0, ns * ha.ring_stride * sizeof(float), st) != hipSuccess ) {
+		if ( scratch_tw ) (void)hipFreeAsync(scratch_tw, st);
+		return -ENOMEM;
+	    }
+	    ha.d_ring = (float *)scratch_ring;
 	}
-	ha.d_ring = (float *)scratch_ring;
     }
     int rc;
     if ( ha.chain_ok ) {
@@ -928,6 +934,60 @@ extern "C" int mifsk_demod_slab( mifsk_ctx *ctx, const mifsk_rx_config *cfg, con
     if ( use_workgroup_engine(cfg, d, io->flags) )
 	return demod_batch_workgroup(ctx, cfg, d, d_cfg, d_tw, io, stream, nullptr, d_state, d_origin, final != 0);
     return demod_batch_wave(ctx, cfg, d, d_cfg, d_tw, io, stream, nullptr, d_state, d_origin, final != 0, &tables);
+}
+
+// floats per stream of the buffer mifsk_demod_slab_ring keeps the reference's samplebuf in
+extern "C" size_t mifsk_ring_floats( const mifsk_rx_config *cfg )
+{
+    if ( mifsk_check_cfg(cfg) )
+	return 0;
+    DevCfg *d = new (std::nothrow) DevCfg();
+    if ( !d )
+	return 0;
+    mifsk::fill_devcfg(*d, *cfg);
+    const size_t reach = (size_t)( cfg->try_max[0] > cfg->try_max[1] ? cfg->try_max[0] : cfg->try_max[1] )
+		       + d->last_reach + 64;
+    delete d;
+    return ( (size_t)cfg->samplebuf_size + reach + 3 ) & ~(size_t)3;
+}
+
+// mifsk_demod_slab with the reference's buffer semantics (MIFSK_IO_RING_EXACT) for streams fed
+// in pieces: the samplebuf cells -- stale ones behind samples_nvalid included -- persist in
+// d_ring between the calls (minimodem.c:1150-1156)
+extern "C" int mifsk_demod_slab_ring( mifsk_ctx *ctx, const mifsk_rx_config *cfg, const mifsk_demod_io *io,
+	mifsk_stream_state *d_state, const uint64_t *d_origin, float *d_ring, int final, void *stream )
+{
+    if ( !ctx || !io || !d_state || !d_ring || mifsk_check_cfg(cfg) )
+	return -EINVAL;
+    if ( io->nstreams < 0 || ( io->nstreams > 0 && !io->d_samples ) )
+	return -EINVAL;
+    if ( io->stream_stride % 4 != 0 || ( (uintptr_t)io->d_samples & 15u ) )
+	return -EINVAL;
+    if ( ( io->d_bytes || io->d_bits || io->d_frames ) && io->frames_cap == 0 )
+	return -EINVAL;
+    if ( io->flags & ~( MIFSK_IO_ENGINE_WAVE | MIFSK_IO_RING_EXACT ) )	// (RING addressing is the wavefront engine's)
+	return -EINVAL;
+    HIP_OK(hipSetDevice(ctx->device));
+    cache_gc(ctx);
+    std::shared_lock<std::shared_mutex> gate(ctx->gate);	// lookup .. enqueue
+    const double *d_tw = nullptr;
+    int rc = get_twiddles(ctx, TwKey{(unsigned)cfg->fftsize, cfg->b_mark, cfg->b_space,
+				     cfg->bit_nsamples}, &d_tw);
+    if ( rc )
+	return rc;
+    DevCfg d;
+    mifsk::fill_devcfg(d, *cfg);
+    const DevCfg *d_cfg = nullptr;
+    CfgEntry tables;
+    rc = get_devcfg(ctx, d, &d_cfg, &tables);
+    if ( rc )
+	return rc;
+    if ( io->nstreams == 0 )
+	return 0;
+    mifsk_demod_io rio = *io;
+    rio.flags |= MIFSK_IO_RING_EXACT;
+    return demod_batch_wave(ctx, cfg, d, d_cfg, d_tw, &rio, stream, nullptr, d_state, d_origin, final != 0,
+			    &tables, d_ring);
 }
 
 // what mifsk_demod_batch would launch for this configuration and batch size

@@ -1788,23 +1788,20 @@ static int launch_with_workers( const DevCfg &cfg, const DevCfg *d_cfg, const do
     if ( nworkers == 2u && !bell202 )
 	return kNotBell202;
     const size_t lds_all = use_slab ? kLdsHeader + slab_floats * 4 : kLdsHeader + 16;
-    // Chained launches (as in launch_demod_wave): a batch of more streams than
-    // the chip holds at once is cut into G groups of streams x K time chunks, each (group,
-    // chunk) its own grid of the RESUMABLE instantiation on the group's stream.  A chunk of this
-    // engine restarts with a search and a pipeline fill (~10 us per stream), so chunks are long:
-    // at least 32 samplebufs, at most four per stream.
+    // Chained launches (as in launch_demod_wave): the batch cut into G groups of
+    // streams x K time chunks, each (group, chunk) its own grid of the RESUMABLE instantiation on
+    // the group's stream.  The mechanism is the wavefront engine's and gives the single launch's
+    // results bit for bit (tests/test_gpu_chain.py) -- but this engine's library default is ONE
+    // launch at every batch size: its streams are short chains (0.45 ms for 10 s of Bell-202), the
+    // dispatcher refills a finished workgroup's slot with the next stream anyway, and every chunk
+    // restarts with a search and a pipeline fill.  Measured (tools/gpu/wg_chain_sizes.py,
+    // profiles/r04_history.md): 1536 / 3000 / 5000 streams 0.825 / 1.43 / 2.16 ms in one launch,
+    // 0.84-0.90 / 1.43-1.52 / 2.24-2.38 chained (2x2 ... 3x3).  MIFSK_CHAIN forces a cut
+    // (experiments and tests).
     uint32_t chain_g = 0, chain_k = 0;
     if ( wh ) {
-	const uint32_t by_lds = (uint32_t)( kLdsPerCu / lds_all );
-	const uint32_t by_regs = 12u / ( nworkers + 1u );	// three waves per SIMD
-	const uint64_t slots = (uint64_t)( by_lds < by_regs ? by_lds : by_regs ) * (uint64_t)( wh->ncu > 0 ? wh->ncu : 1 );
 	const bool allowed = ( plan_only ? wh->chain_ok : wh->chain != nullptr ) && !wh->d_state
 			  && !io.d_counters && io.nstreams > 0;
-	if ( allowed && (uint64_t)io.nstreams > slots && wh->samplebuf_size > 0u ) {
-	    chain_g = 2u;
-	    chain_k = io.nsamples / ( 32u * wh->samplebuf_size );
-	    if ( chain_k > 4u ) chain_k = 4u;
-	}
 	if ( const char *e = experiment_env("MIFSK_CHAIN") ) {	// experiments and tests only: "G,K", any batch
 	    int a = 0, b = 0;
 	    if ( allowed && std::sscanf(e, "%d,%d", &a, &b) == 2 ) {

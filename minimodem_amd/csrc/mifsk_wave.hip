@@ -1346,9 +1346,24 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 	// ------------------------------------------------------------------
 	// one iteration of the reference's loop
 	// ------------------------------------------------------------------
-	if ( !last_slab && (uint64_t)base + advance + bufsize > (uint64_t)N ) {
-	    paused = true;			// it could read beyond the row: the next slab resumes here
-	    break;
+	if ( !last_slab ) {
+	    if ( RA && ring ) {
+		// RING addressing with more of the stream to come: a search reads nothing beyond
+		// samples_nvalid that is not in the (persistent) ring already, so a pass needs
+		// exactly what the reference's fread would deliver -- a full half buffer whenever
+		// fewer than half is valid after the shift (minimodem.c:1146-1174)
+		const uint64_t nb = (uint64_t)base + advance;
+		const uint64_t nrp = advance == bufsize ? nb : (uint64_t)rp;
+		if ( nrp < nb || nrp - nb < (uint64_t)half ) {
+		    if ( nrp > (uint64_t)N || (uint64_t)N - nrp < (uint64_t)half ) {
+			paused = true;		// the refill is not in the row yet
+			break;
+		    }
+		}
+	    } else if ( (uint64_t)base + advance + bufsize > (uint64_t)N ) {
+		paused = true;			// it could read beyond the row: the next slab resumes here
+		break;
+	    }
 	}
 	if ( advance == bufsize ) {				// minimodem.c:1146-1149: samples_nvalid = 0
 	    base += advance;
