@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""8-GPU readiness without the node: what does a CU-resident copy cost the
+demod launch it shares the chip with?  At N = 8 the root receives 7 peers' decoded bytes per step
+through RCCL copy kernels while its own demod kernel runs (configs[3]: 7 x 19.7 MB per 1.3 ms
+step; configs[1]: 7 x 1.2 MB per 0.45 ms).  Here: the config's kernel alone, then with a
+device-to-device copy of that many bytes per step running concurrently on a second stream -- a
+plain torch copy kernel, which takes as many CUs as it likes: an upper bound on what RCCL's few
+channel workgroups do."""
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import bench
+import torch
+import minimodem_amd as M
+
+ctx = M.Context(0)
+out = {}
+for name in ("1200", "12000"):
+    entry, mode, per_gpu, seconds, _, amplitude = bench.WORKLOADS[name]
+    cfg = M.rx_config(mode)
+    nsamp = 480000 if name == "1200" else int(seconds * cfg.sample_rate)
+    rng = np.random.default_rng(9)
+    frame = (cfg.n_data_bits + cfg.nstartbits + cfg.nstopbits) * cfg.nsamples_per_bit
+    nwords = int((nsamp - 6 * cfg.nsamples_per_bit - 41) / frame) - 2
+    words = torch.from_numpy(rng.integers(0x20, 0x7F, size=(per_gpu, nwords), dtype=np.uint8)).cuda()
+    lead = torch.from_numpy(rng.integers(0, 41, size=per_gpu).astype(np.int32)).cuda()
+    x, lens = M.synthesize_batch(ctx, cfg, words, stride=(nsamp + 3) & ~3, leading_silence=lead)
+    cols = int(M.max_frames(cfg, nsamp))
+    gather_bytes = 7 * (per_gpu * cols + 4 * per_gpu)
+    src = torch.empty(gather_bytes, dtype=torch.uint8, device="cuda")
+    dst = torch.empty_like(src)
+    side = torch.cuda.Stream()
+    res = M.demod_batch(ctx, cfg, x, nsamples=lens, want=("bytes",))
+    torch.cuda.synchronize()
+
+    def run(with_copy, reps=12):
+        ts = []
+        for _ in range(reps):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            if with_copy:
+                with torch.cuda.stream(side):
+                    for _ in range(2):          # (keeps copying while the kernel runs)
+                        dst.copy_(src)
+            e0.record()
+            M.demod_batch(ctx, cfg, x, nsamples=lens, want=("bytes",), out=res)
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return float(np.median(ts))
+
+    alone = run(False)
+    shared = run(True)
+    out[name] = {"kernel_ms_alone": alone, "kernel_ms_beside_copy": shared, "slowdown": shared / alone,
+                 "copy_bytes_per_step": gather_bytes}
+    print(name, json.dumps(out[name]), flush=True)
+    del x, src, dst
+    torch.cuda.empty_cache()
