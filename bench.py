@@ -197,17 +197,19 @@ def hbm_traffic(name):
     under profiles/ for this workload by tools/profile_round.sh -- reported only while the record
     was taken with the kernel sources that are running now; None otherwise (a stale ratio would
     silently survive a kernel change)."""
-    path = os.path.join(ROOT, "profiles", "r03_%s_hbm_traffic.json" % name)
-    try:
-        with open(path) as f:
-            rec = json.load(f)
-        if rec.get("kernel_source_id") != kernel_source_id():
-            return None
-        return {"bytes_per_launch": rec["hbm_bytes_per_launch"],
-                "source": "profiles/r03_%s_hbm_traffic.json" % name,
-                "fetch_size_kb_raw": rec["fetch_size_kb_raw"], "write_size_kb_raw": rec["write_size_kb_raw"]}
-    except Exception:
-        return None
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_%s_hbm_traffic.json" % name)), reverse=True):
+        try:
+            with open(path) as f:
+                rec = json.load(f)
+            if rec.get("kernel_source_id") != kernel_source_id():
+                continue
+            return {"bytes_per_launch": rec["hbm_bytes_per_launch"],
+                    "source": "profiles/" + os.path.basename(path),
+                    "fetch_size_kb_raw": rec["fetch_size_kb_raw"], "write_size_kb_raw": rec["write_size_kb_raw"]}
+        except Exception:					# noqa: BLE001
+            continue
+    return None
 
 
 class RankFailed(RuntimeError):

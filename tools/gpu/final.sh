@@ -1,10 +1,10 @@
 set -u
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/final; mkdir -p $O
-timeout 2400 python -m pytest tests -q -m gpu --timeout 900 2>&1 | tail -4
+timeout -s KILL 1200 python -m pytest tests -q -m gpu --timeout 300 -p no:cacheprovider 2>&1 | tail -4
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-bash tools/profile_round.sh r03 "1200 rtty 12000 same" > $O/profile.log 2>&1
-timeout 900 python bench.py > $O/bench.json 2>$O/bench.err; echo "bench rc=$?"
+bash tools/profile_round.sh ${TAG:-r04} "1200 rtty 12000 same" > $O/profile.log 2>&1
+timeout -s KILL 600 python bench.py > $O/bench.json 2>$O/bench.err; echo "bench rc=$?"
 python - <<'PY'
 import json
 l = json.loads(open('gpurun_out/final/bench.json').read().strip().splitlines()[-1])

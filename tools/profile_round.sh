@@ -1,11 +1,11 @@
 #!/bin/bash
 # Collect the round's profiling evidence on the GPU box (run through gpurun):
-#   tools/profile_round.sh r03 "1200 rtty 12000 same"
+#   tools/profile_round.sh ${TAG:-r04} "1200 rtty 12000 same"
 # Writes under gpurun_out/profile_<tag>_<config>/ ; tools/summarize_profile.py copies the
 # summaries into profiles/.  PMC counters are collected in their own passes with
 # --kernel-trace only (never together with other tracing domains).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 CONFIGS=${2:-"1200 rtty 12000 same"}
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 for C in $CONFIGS; do
