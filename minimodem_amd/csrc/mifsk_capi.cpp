@@ -602,6 +602,29 @@ static int get_cs( mifsk_ctx *ctx, unsigned N, const double **d_out )
     return 0;
 }
 
+// fill_devcfg through the context's small cache (keyed by the configuration's bytes: two equal
+// byte strings are equal configurations; unequal padding only costs a miss)
+static void derive_cfg( mifsk_ctx *ctx, const mifsk_rx_config &cfg, DevCfg &d )
+{
+    {
+	std::lock_guard<std::mutex> g(ctx->lock);
+	for ( const mifsk_ctx::DerivedCfg &e : ctx->derived )
+	    if ( std::memcmp(&e.key, &cfg, sizeof(cfg)) == 0 ) {
+		d = e.d;
+		return;
+	    }
+    }
+    mifsk::fill_devcfg(d, cfg);
+    std::lock_guard<std::mutex> g(ctx->lock);
+    constexpr size_t kKeep = 8;
+    if ( ctx->derived.size() < kKeep ) {
+	ctx->derived.push_back(mifsk_ctx::DerivedCfg{cfg, d});
+    } else {
+	ctx->derived[ctx->derived_next % kKeep] = mifsk_ctx::DerivedCfg{cfg, d};
+	ctx->derived_next++;
+    }
+}
+
 int mifsk_check_cfg( const mifsk_rx_config *cfg )
 {
     if ( !cfg || cfg->expect_n_bits == 0 || cfg->expect_n_bits > MIFSK_MAX_FRAME_BITS
@@ -629,7 +652,7 @@ extern "C" int mifsk_find_frame_batch( mifsk_ctx *ctx, const mifsk_rx_config *cf
     if ( rc )
 	return rc;
     DevCfg d;
-    mifsk::fill_devcfg(d, *cfg);
+    derive_cfg(ctx, *cfg, d);
     const DevCfg *d_cfg = nullptr;
     rc = get_devcfg(ctx, d, &d_cfg);
     if ( rc )
@@ -823,7 +846,7 @@ static int demod_batch_workgroup( mifsk_ctx *ctx, const mifsk_rx_config *cfg, co
     wh.chain_ok = !d_state && !io->d_counters;
     if ( plan_only )
 	return mifsk::launch_demod_batch(d, d_cfg, d_tw, *io, stream, plan_only, &wh);
-    if ( wh.chain_ok ) {
+    if ( wh.chain_ok && mifsk::experiment_env("MIFSK_CHAIN") ) {	// (this engine's default is one launch)
 	mifsk::LaunchInfo li;
 	std::memset(&li, 0, sizeof(li));
 	int rc = mifsk::launch_demod_batch(d, d_cfg, d_tw, *io, stream, &li, &wh);
@@ -867,7 +890,7 @@ extern "C" int mifsk_demod_batch( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
     if ( rc )
 	return rc;
     DevCfg d;
-    mifsk::fill_devcfg(d, *cfg);
+    derive_cfg(ctx, *cfg, d);
     const DevCfg *d_cfg = nullptr;
     CfgEntry tables;
     rc = get_devcfg(ctx, d, &d_cfg, &tables);
@@ -923,7 +946,7 @@ extern "C" int mifsk_demod_slab( mifsk_ctx *ctx, const mifsk_rx_config *cfg, con
     if ( rc )
 	return rc;
     DevCfg d;
-    mifsk::fill_devcfg(d, *cfg);
+    derive_cfg(ctx, *cfg, d);
     const DevCfg *d_cfg = nullptr;
     CfgEntry tables;
     rc = get_devcfg(ctx, d, &d_cfg, &tables);
@@ -976,7 +999,7 @@ extern "C" int mifsk_demod_slab_ring( mifsk_ctx *ctx, const mifsk_rx_config *cfg
     if ( rc )
 	return rc;
     DevCfg d;
-    mifsk::fill_devcfg(d, *cfg);
+    derive_cfg(ctx, *cfg, d);
     const DevCfg *d_cfg = nullptr;
     CfgEntry tables;
     rc = get_devcfg(ctx, d, &d_cfg, &tables);
@@ -1003,7 +1026,7 @@ extern "C" int mifsk_demod_plan_ex( mifsk_ctx *ctx, const mifsk_rx_config *cfg, 
     if ( !ctx || !out || mifsk_check_cfg(cfg) || nstreams < 0 )
 	return -EINVAL;
     DevCfg d;
-    mifsk::fill_devcfg(d, *cfg);
+    derive_cfg(ctx, *cfg, d);
     mifsk_demod_io io;
     std::memset(&io, 0, sizeof(io));
     io.nstreams = nstreams;

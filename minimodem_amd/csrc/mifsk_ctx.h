@@ -56,6 +56,12 @@ struct mifsk_ctx {
     size_t		table_bytes = 0;	// twiddle tables held
     std::vector<TwEntry>	tables;
     std::vector<CfgEntry>	configs;
+    // the derived kernel configuration of the configurations seen last (fill_devcfg plans the
+    // shared segments of every scan: 0.3 ms for RTTY -- per call, on the launch path, it was
+    // 3 % of that kernel's time): a few entries, replaced round-robin
+    struct DerivedCfg { mifsk_rx_config key; DevCfg d; };
+    std::vector<DerivedCfg>	derived;
+    size_t		derived_next = 0;
     // (the spectrum table of fsk_detect_carrier is a TwEntry with bit_nsamples == 0)
     // the host-memory pipeline's streams, events and pinned staging (mifsk_hostpipe.cpp)
     mifsk::HostWork	*host = nullptr;

@@ -4,6 +4,7 @@ payloads, amplitudes, leading silence, additive noise, DC offset, clipping, rate
 slop (resampled TX rate) and truncation; every frame record and episode from the
 device must equal the oracle's bit for bit.   python tools/soak.py [--seed N] [--streams N]"""
 import argparse
+from concurrent.futures import ThreadPoolExecutor
 import os
 import sys
 import time
@@ -96,7 +97,8 @@ def main():
         if args.slabs:
             # every stream cut at its own random places; the pieces' outputs concatenated
             cuts = [sorted(int(c) for c in rng.integers(0, len(s) + 1, size=args.slabs - 1)) for s in streams]
-            sess = M.SlabSession(ctx, cfg, len(streams), episodes_cap=64)
+            sess = M.SlabSession(ctx, cfg, len(streams), episodes_cap=64, ring_exact=args.ring,
+                                 engine=None if args.ring or kw.get("auto_carrier_threshold") else args.engine)
             acc = [dict(frames=[], episodes=[], bytes=b"") for _ in streams]
             for k in range(args.slabs):
                 new = []
@@ -115,8 +117,10 @@ def main():
                                                   want=("bytes", "frames") if args.no_episodes else ("bytes", "frames", "episodes"),
                                                   episodes_cap=64,
                                                   engine=args.engine, ring_exact=args.ring))
-        nf = 0
-        for i, s in enumerate(streams):
+        # the oracle over every stream on all host cores (ofsk_rx_stream is re-entrant, ctypes
+        # releases the GIL)
+        def check(i):
+            s = streams[i]
             ref = O.oracle_rx_stream(ocfg, s, ring_mode=args.ring)
             if args.slabs:
                 fr = np.concatenate(acc[i]["frames"])
@@ -132,11 +136,16 @@ def main():
                       and res["bytes"][i, :int(res["nbytes"][i])].tobytes() == ref["bytes"])
                 if not args.no_episodes:
                     ok = ok and ne == len(ref["episodes"]) and res["episodes"][i, :ne].tobytes() == ref["episodes"].tobytes()
-            if not ok:
-                bad += 1
-                print("MISMATCH mode %s %r stream %d (len %d): gpu %d frames, oracle %d"
-                      % (mode, kw, i, len(s), n, len(ref["frames"])))
-            nf += n
+            return ok, n, len(ref["frames"])
+
+        nf = 0
+        with ThreadPoolExecutor(max_workers=os.cpu_count() or 1) as ex:
+            for i, (ok, n, nref) in enumerate(ex.map(check, range(len(streams)))):
+                if not ok:
+                    bad += 1
+                    print("MISMATCH mode %s %r stream %d (len %d): gpu %d frames, oracle %d"
+                          % (mode, kw, i, len(streams[i]), n, nref))
+                nf += n
         total_frames += nf
         print("%-6s %-40s %4d streams %7d frames  %.1f s%s" % (mode, kw, len(streams), nf, time.time() - t, cut))
     print("seed %d (%s engine, %s addressing%s): %d frames compared, %d mismatching streams"
