@@ -336,7 +336,11 @@ def oracle_verdict(name, mode, M, torch, ctx, cfg, samples, lens, kw, frames_cap
         t0 = time.perf_counter()
         bad, by_group, secs = O.oracle_batch_mismatches(O.oracle_config(mode), samples, lens, res,
                                                         threads=threads, groups=groups)
+        nsamp_total = float(samples.shape[0] * samples.shape[1] if lens is None else int(lens.sum()))
         v = {"streams": int(samples.shape[0]), "mismatching_streams": len(bad),
+             # (the restated loop on every host core at once: the strongest CPU figure of this
+             # line -- samples of the shard / wall time of the oracle pass, D2H not included)
+             "samples_per_s_all_cores": nsamp_total / max(secs, 1e-9),
              "compared": "every stream: nframes, frame records (bits, start, flags, confidence and "
                          "amplitude bit patterns), episodes, bytes",
              "threads": threads, "oracle_seconds": secs, "seconds": time.perf_counter() - t0}
