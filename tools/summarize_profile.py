@@ -69,7 +69,7 @@ def code_object_figures(kernel):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
     configs = sys.argv[2:] or ["1200"]
     dst = os.path.join(ROOT, "profiles")
     ksid = bench.kernel_source_id()
