@@ -1385,8 +1385,12 @@ __device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const 
 	// The same share of the next round (of this batch or the next), assuming
 	// the lattice goes on; issued unconditionally and with no control flow
 	// after it (see worker_lattice).  (A second, alternating register buffer
-	// -- two rounds of look-ahead -- does not fit the 128-VGPR budget that
-	// four workgroups per CU impose: it spills into the hot loop.)
+	// -- two rounds of look-ahead -- does not fit: measured again in round 4 on the
+	// Bell-202 instantiation at its 168-VGPR budget, 33 VGPRs spill into this
+	// loop and configs[1] goes 0.465 -> 0.555 ms.  Staging by LDS-DMA instead
+	// needs the landing zone in LDS, which four workgroups per CU do not leave;
+	// and with one round of look-ahead the memory system already delivers
+	// 6.1 TB/s to this access pattern: profiles/r04_history.md.)
 	{
 	    const uint32_t nlo = lo + lat_frames * cfg.lock_advance;
 	    const bool ok = nlo >= lo && nlo <= safe_limit - kRoundFloats;
