@@ -738,6 +738,22 @@ __device__ __forceinline__ void corr_lds_fixed( const TwGroup (&tg)[3], const fl
     for ( int q = 0; q < NQ; q++ )
 	xs[q] = *reinterpret_cast<const float4 *>(p + 4 * q);
     dpp_settle();
+    if constexpr ( NQ == 1 ) {
+	// A window of four samples (12000 baud at 48 kHz): sample 0's four FMAs and the zeroing
+	// of the accumulators are a fifth of its arithmetic.  Entry 0 of both tables is exactly
+	// (1.0, -0.0) (cos 0, -sin 0), and the caller's accumulators are +0.0: fma(x, 1.0, +0.0)
+	// is x, fma(x, -0.0, +0.0) is x * -0.0 -- up to the SIGN of a zero, which no later
+	// operation can see (it is added to, and squared); NaN and infinity propagate the same.
+	const double x0 = (double)xs[0].x;
+	acc[0] = x0;
+	acc[2] = x0;
+	acc[1] = x0 * -0.0;
+	acc[3] = acc[1];
+	fma4_bcast<1>(acc, tg[0], xs[0].y);
+	fma4_bcast<2>(acc, tg[0], xs[0].z);
+	fma4_bcast<3>(acc, tg[0], xs[0].w);
+	return;
+    }
 #define MIFSK_QUAD(Q)							\
     if ( (Q) < NQ ) {							\
 	if ( (Q) % 4 == 0 ) quad_bcast<0>(acc, tg[(Q) / 4], xs[(Q) < NQ ? (Q) : 0]);	\

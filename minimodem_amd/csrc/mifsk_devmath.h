@@ -35,7 +35,9 @@ __device__ __forceinline__ double sqrt_sumsq( double s )
 __device__ __forceinline__ float band_mag( double re, double im, float scalar )
 {
     const float fr = (float)re, fi = (float)im;
-    const double s = (double)fr * (double)fr + (double)fi * (double)fi;
+    // (the squares of two floats are exact in double, so the one rounding of their sum is
+    // the fma's: the same s as mul, mul, add with an instruction less)
+    const double s = __builtin_fma((double)fr, (double)fr, (double)fi * (double)fi);
     return (float)sqrt_sumsq(s) * scalar;
 }
 

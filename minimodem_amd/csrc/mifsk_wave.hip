@@ -277,7 +277,8 @@ struct Wave {
     __device__ __forceinline__ uint32_t win_rel( uint32_t w ) const
     {
 	if ( cfg.lat_grid )
-	    return w * cfg.bit_nsamples;
+	    return NQ > 0 ? w * (uint32_t)( 4 * ( NQ > 0 ? NQ : 1 ) )	// (this instantiation's bit length: a shift)
+			  : w * cfg.bit_nsamples;
 	const uint32_t f = udiv_magic(w, cfg.n_bits, cfg.nbits_magic);
 	return f * cfg.lock_advance + cfg.bit_offset[( w - f * cfg.n_bits ) & 63u];
     }
@@ -350,7 +351,12 @@ struct Wave {
 	for ( uint32_t s0 = 0; s0 < nw; s0 += 64u ) {
 	    const uint32_t w = w0 + s0 + lane;
 	    const bool active = s0 + lane < nw;
-	    const uint32_t rel = A + win_rel(active ? w : w0) - lo;	// idle lanes shadow the first window
+	    // (idle lanes shadow the round's first window)
+	    uint32_t rel;
+	    if ( NQ > 0 && cfg.lat_grid )	// window w starts w * B past the anchor: (w - w0) * B past `lo`
+		rel = ( active ? s0 + lane : 0u ) * (uint32_t)( 4 * ( NQ > 0 ? NQ : 1 ) );
+	    else
+		rel = A + win_rel(active ? w : w0) - lo;
 	    double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
 	    if constexpr ( NQ > 0 )
 		corr_lds_fixed<NQ>(tgr, slab + rel, acc);	// the instantiation for this bit length
