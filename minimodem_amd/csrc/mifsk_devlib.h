@@ -130,10 +130,50 @@ frame_confidence( const float2 *mags, uint64_t req_mask, uint64_t req_val, uint3
     return out;
 }
 
+// 1 / c for a finite, non-zero float c, in double, to within 2^-52 relative: v_rcp_f64 and
+// two Newton steps.
+__device__ __forceinline__ double rcp_of_float( float c )
+{
+    const double d = (double)c;
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(e, r, r);
+    e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(e, r, r);
+    return r;
+}
+
+// IEEE float division x / c through a reciprocal in double: (float)((double)x * rc) with
+// rc = rcp_of_float(c).  EXACT -- the correctly rounded quotient -- whenever the result is a
+// normal float (or zero, infinite or NaN): the exact quotient of two 24-bit significands lies
+// at least 2^-48 (relative) away from every midpoint of two adjacent floats (X / C - M / 2^24
+// = (X 2^24 - M C) / (C 2^24), a non-zero integer over less than 2^48), and x * rc is within
+// 2^-51 of it, so rounding the double to float cannot cross a midpoint.  (Ties exist only for
+// denormal results: callers fall back to the division there.)  Three instructions per quotient
+// where the division takes ten -- and the reference's divergence pass divides the eleven bits
+// of a frame by one of only two class means (fsk.c:305-313).
+__device__ __forceinline__ float div_by_rcp( float x, double rc )
+{
+    return (float)( (double)x * rc );
+}
+
+__device__ __forceinline__ bool float_is_plain( float c )	// finite and not zero
+{
+    return c != 0.0f && fabsf(c) < INFINITY;			// (false for NaN)
+}
+
+__device__ __forceinline__ bool float_is_subnormal( float t )
+{
+    return t != 0.0f && fabsf(t) < FLT_MIN;
+}
+
 // The same for a frame length known at compile time: every magnitude is loaded
 // once (all loads in flight together), the per-bit signal levels stay in
 // registers for the divergence pass, nothing is computed for padding slots.
-// Operation for operation the sequence above.
+// Operation for operation the sequence above -- with the divisions of the divergence pass
+// and the two by the constant frame length made through reciprocals (div_by_rcp: the same
+// quotients, bit for bit; any lane whose divisor or result is not a plain float sends its
+// wave through the divisions proper).
 template <int NB>
 __device__ __forceinline__ FrameOut
 frame_confidence_fixed( const float2 *mags, uint64_t req_mask, uint64_t req_val )
@@ -173,24 +213,48 @@ frame_confidence_fixed( const float2 *mags, uint64_t req_mask, uint64_t req_val 
     const uint32_t n_space = (uint32_t)NB - n_mark;
 
     const float snr = total_sig / total_noise;		// fsk.c:292
-    const float avg_sig = total_sig / (float)NB;	// fsk.c:295
+    constexpr double kRcpNB = 1.0 / (double)NB;
+    float avg_sig = div_by_rcp(total_sig, kRcpNB);	// fsk.c:295
     if ( n_mark )
 	mark_sig /= (float)n_mark;			// fsk.c:298-301
     if ( n_space )
 	space_sig /= (float)n_space;
 
     float term[NB];					// fsk.c:305-313
+    const double rc_mark = rcp_of_float(mark_sig), rc_space = rcp_of_float(space_sig);
+    bool odd = ( n_mark && !float_is_plain(mark_sig) ) || ( n_space && !float_is_plain(space_sig) )
+	    || float_is_subnormal(avg_sig);
 #pragma unroll
     for ( int k = 0; k < NB; k++ ) {
-	const float cls = ( bits >> k ) & 1u ? mark_sig : space_sig;
-	term[k] = fabsf(sig[k] - cls) / cls;
+	const bool one = ( bits >> k ) & 1u;
+	const float cls = one ? mark_sig : space_sig;
+	term[k] = div_by_rcp(fabsf(sig[k] - cls), one ? rc_mark : rc_space);
+	odd = odd || float_is_subnormal(term[k]);
     }
     float divergence = 0.0f;
 #pragma unroll
     for ( int k = 0; k < NB; k++ )
 	divergence += term[k];
     divergence *= 2.0f;
-    divergence /= (float)NB;
+    float div_n = div_by_rcp(divergence, kRcpNB);
+    odd = odd || float_is_subnormal(div_n);
+    if ( __any(odd) ) {
+	// a divisor that is zero, infinite or NaN, or a subnormal quotient, somewhere in the
+	// wave: the divisions proper, for everybody (uniform branch, practically never taken)
+	avg_sig = total_sig / (float)NB;
+#pragma unroll
+	for ( int k = 0; k < NB; k++ ) {
+	    const float cls = ( bits >> k ) & 1u ? mark_sig : space_sig;
+	    term[k] = fabsf(sig[k] - cls) / cls;
+	}
+	divergence = 0.0f;
+#pragma unroll
+	for ( int k = 0; k < NB; k++ )
+	    divergence += term[k];
+	divergence *= 2.0f;
+	div_n = divergence / (float)NB;
+    }
+    divergence = div_n;
 
     out.conf = snr * (1.0f - divergence);		// fsk.c:336
     out.ampl = avg_sig;					// fsk.c:342
