@@ -14,6 +14,9 @@ entries (same JSON shape, `config.workload` names the entry):
     12000   configs[3]  12000 baud, 8192 streams x 2 s per GPU (65536 over 8 GPUs)
     same    configs[4]  NOAA SAME 520.83 baud, 8192 streams x 10 s per GPU, amplitude 0.5,
                         AWGN SNR sweep inf/20/12/9/6/3 dB + the reference's DC-offset sweep
+    1200noise           configs[1]'s batch under the impairments the reference's own noise tests
+                        apply at 1200 baud (tests/40-noise.test:14-20): clean, AWGN 20/12/9/6 dB,
+                        DC offset 0.05/0.10/0.50, interleaved over the 1024 streams
 
 One "step" = one pass of the receive path over the whole resident batch
 (mifsk_demod_batch: frame search + bit correlation + receive loop on the device)
@@ -62,9 +65,45 @@ WORKLOADS = {
               "12000", 8192, 2.0, (0x20, 0x7F), 1.0),
     "same": ("configs[4]: NOAA SAME 520.83-baud with additive-noise SNR sweep (tests/40-style)",
              "same", 8192, 10.0, (0x20, 0x7F), 0.5),
+    # not a BASELINE entry of its own: configs[1]'s workload, same size, under impairments --
+    # what the headline kernel (which speculates on the lock holding) does when it breaks
+    "1200noise": ("configs[1] under impairments: Bell202 1200-baud, 48 kHz f32, 1024 streams, clean / AWGN "
+                  "20, 12, 9, 6 dB / DC offset 0.05, 0.10, 0.50 interleaved (reference tests/40-noise.test:14-20)",
+                  "1200", 1024, NSAMPLES / 48000.0, (0x20, 0x7F), 1.0),
 }
+# conditions interleaved over a batch by GLOBAL stream id (stream g gets condition g % len):
+# the SNR sweep of SURVEY 8(d) plus the reference's whole DC-offset list (tests/40-noise.test:20:
+# 0.0 0.05 0.10 0.50)
 SAME_CONDITIONS = [("snr_db", None), ("snr_db", 20), ("snr_db", 12), ("snr_db", 9), ("snr_db", 6),
-                   ("snr_db", 3), ("dc", 0.05), ("dc", 0.50)]
+                   ("snr_db", 3), ("dc", 0.05), ("dc", 0.10), ("dc", 0.50)]
+NOISE1200_CONDITIONS = [("snr_db", None), ("snr_db", 20), ("snr_db", 12), ("snr_db", 9), ("snr_db", 6),
+                        ("dc", 0.05), ("dc", 0.10), ("dc", 0.50)]
+CONDITIONS = {"same": SAME_CONDITIONS, "1200noise": NOISE1200_CONDITIONS}
+# conditions under which the payload is not expected to survive (not a pass criterion)
+LOSSY = (("snr_db", 12), ("snr_db", 9), ("snr_db", 6), ("snr_db", 3))
+
+
+def condition_label(kind, v):
+    return "clean" if v is None else ("%g dB SNR" % v if kind == "snr_db" else "DC offset %g" % v)
+
+
+def apply_conditions(name, torch, samples, lens, lo, rank, amplitude):
+    """AWGN at the condition's SNR (signal power amplitude^2 / 2, seeded per rank) or the
+    reference's --Xrxnoise DC term, condition (lo + i) % len(conditions) on row i; the rows'
+    zero padding beyond their length stays zero."""
+    conds = CONDITIONS[name]
+    nc = len(conds)
+    p_sig = amplitude ** 2 / 2
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1000 + rank)
+    for k, (kind, v) in enumerate(conds):
+        first = (k - lo) % nc
+        rows = samples[first::nc]
+        if kind == "snr_db" and v is not None:
+            sigma = float(np.sqrt(p_sig / 10 ** (v / 10)))
+            rows += torch.randn(rows.shape, generator=g, device="cuda", dtype=torch.float32) * sigma
+        elif kind == "dc":
+            rows -= np.float32(v)
 
 
 def make_stream(M, cfg, gid):
@@ -245,7 +284,7 @@ def run_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, cp
         total_streams = per_gpu * world
     lo, hi = M.shard_range(total_streams, rank, world)
     nstreams = hi - lo
-    nsamp = NSAMPLES if name == "1200" else int(seconds * cfg.sample_rate)
+    nsamp = NSAMPLES if name in ("1200", "1200noise") else int(seconds * cfg.sample_rate)
     stride = (nsamp + 3) & ~3
 
     # ---- synthetic batch, resident in HBM before anything is timed ----------
@@ -276,7 +315,7 @@ def run_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, cp
 
 def make_batch(name, M, torch, ctx, cfg, rank, lo, nstreams, nsamp, stride, amplitude, payloads):
     """the rank's shard of the synthetic batch -> (samples on the device, lengths or None)"""
-    if name == "1200":
+    if name in ("1200", "1200noise"):
         # host generator (threaded; it releases the GIL)
         host = np.zeros((nstreams, stride), np.float32)
 
@@ -290,6 +329,8 @@ def make_batch(name, M, torch, ctx, cfg, rank, lo, nstreams, nsamp, stride, ampl
         samples = torch.from_numpy(host).cuda()
         lens = None
         del host
+        if name == "1200noise":
+            apply_conditions(name, torch, samples, lens, lo, rank, amplitude)
     else:
         # device generator (mifsk_tx_synthesize_batch; bit-identical to the host one)
         wl = [stream_words(name, cfg, lo + i, nsamp) for i in range(nstreams)]
@@ -302,18 +343,7 @@ def make_batch(name, M, torch, ctx, cfg, rank, lo, nstreams, nsamp, stride, ampl
                                            leading_silence=lead, amplitude=amplitude)
         assert int(lens.max()) <= stride and nw > 0
         if name == "same":
-            # conditions interleaved over the batch by GLOBAL stream id
-            p_sig = amplitude ** 2 / 2
-            g = torch.Generator(device="cuda")
-            g.manual_seed(1000 + rank)
-            for k, (kind, v) in enumerate(SAME_CONDITIONS):
-                first = (k - lo) % 8
-                rows = samples[first::8]
-                if kind == "snr_db" and v is not None:
-                    sigma = float(np.sqrt(p_sig / 10 ** (v / 10)))
-                    rows += torch.randn(rows.shape, generator=g, device="cuda", dtype=torch.float32) * sigma
-                elif kind == "dc":
-                    rows -= np.float32(v)
+            apply_conditions(name, torch, samples, lens, lo, rank, amplitude)
     return samples, lens
 
 
@@ -332,7 +362,8 @@ def oracle_verdict(name, mode, M, torch, ctx, cfg, samples, lens, kw, frames_cap
         res = M.results_to_host(out)
         del out
         threads = max(1, (os.cpu_count() or 1) // max(1, world))
-        groups = (lambda i: (lo + i) % 8) if name == "same" else None
+        nc = len(CONDITIONS[name]) if name in CONDITIONS else 0
+        groups = (lambda i: (lo + i) % nc) if nc else None
         t0 = time.perf_counter()
         bad, by_group, secs = O.oracle_batch_mismatches(O.oracle_config(mode), samples, lens, res,
                                                         threads=threads, groups=groups)
@@ -351,6 +382,25 @@ def oracle_verdict(name, mode, M, torch, ctx, cfg, samples, lens, kw, frames_cap
         return v
     except Exception as e:					# noqa: BLE001
         return {"streams": int(samples.shape[0]), "mismatching_streams": None, "error": repr(e)}
+
+
+def work_counters(name, M, torch, ctx, cfg, samples, lens, kw):
+    """One more untimed pass with the kernels' per-stream work counters: general-path iterations
+    (every pass of the reference's loop the lattice speculation did not cover), refinements
+    (minimodem.c:1357-1389), frames accepted from the lattice.  None if the pass fails."""
+    try:
+        k2 = dict(kw)
+        k2["want"] = ("bytes", "counters")
+        out = M.demod_batch(ctx, cfg, samples, **k2)
+        torch.cuda.synchronize()
+        c = out["counters"].cpu().numpy().view(np.uint64).astype(np.float64)
+        idx = {v: k for k, v in M.COUNTER_NAMES.items()}
+        cols = {"general_path_iterations": c[:, idx["iterations"]], "refinements": c[:, idx["refines"]],
+                "lattice_frames": c[:, idx["bulk_frames"]]}
+        cols["frames"] = out["nframes"].cpu().numpy().astype(np.float64)
+        return cols
+    except Exception:					# noqa: BLE001 -- diagnostic only
+        return None
 
 
 def timed_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, cpu_leg, oracle_leg,
@@ -461,7 +511,7 @@ def timed_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, 
         got = b[:nb].tobytes()
         if name == "1200":
             return got == payload.tobytes()
-        if name == "same" and SAME_CONDITIONS[gid % 8] in (("snr_db", 12), ("snr_db", 9), ("snr_db", 6), ("snr_db", 3)):
+        if name in CONDITIONS and CONDITIONS[name][gid % len(CONDITIONS[name])] in LOSSY:
             return None				# whether it survives the noise is not a criterion
         return payload.tobytes() in got		# (rtty: 5-bit words; the leader may add a frame in front)
 
@@ -472,11 +522,12 @@ def timed_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, 
     # (what the reference's algorithm loses to the noise -- the GPU's frames equal the oracle's
     # either way, tests/test_gpu_fullsize.py -- and what byte error rate is left)
     by_condition = None
-    if name == "same":
+    if name in CONDITIONS:
         by_condition = {}
-        for k, (kind, v) in enumerate(SAME_CONDITIONS):
-            label = "clean" if v is None else ("%g dB SNR" % v if kind == "snr_db" else "DC offset %g" % v)
-            mine = [i for i in range(nstreams) if (lo + i) % 8 == k]
+        work = work_counters(name, M, torch, ctx, cfg, samples, lens, kw) if rank == 0 else None
+        for k, (kind, v) in enumerate(CONDITIONS[name]):
+            label = condition_label(kind, v)
+            mine = [i for i in range(nstreams) if (lo + i) % len(CONDITIONS[name]) == k]
             whole = sent = out = 0
             for i in mine:
                 got = gpu_bytes[i][:int(gpu_nbytes[i])].tobytes()
@@ -490,6 +541,9 @@ def timed_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, 
                 # the decode error rate vs the ORACLE per condition (streams whose
                 # every frame record equals the oracle's on the identical buffer)
                 by_condition[label]["frames_equal_oracle"] = oracle["frames_equal_oracle_by_condition"].get(k)
+            if work is not None:
+                # how often the speculation on the lock breaks under this condition (per stream)
+                by_condition[label]["per_stream"] = {key: float(np.mean(col[mine])) for key, col in work.items()}
     # the bytes gathered from the peers are checked too (rank 0): each peer's streams are
     # regenerated from their global ids
     peers_ok = peers_judged = 0
@@ -501,7 +555,7 @@ def timed_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, 
             pn = rn.cpu().numpy()
             for j in range(phi - plo):
                 gid = plo + j
-                if name == "1200":
+                if name in ("1200", "1200noise"):
                     rng = np.random.default_rng(1234 + gid)
                     lead_ = int(rng.integers(0, 41))
                     pay = rng.integers(0x20, 0x7F, size=(NSAMPLES - lead_ - 4 * 40) // 400, dtype=np.uint8)
@@ -520,7 +574,7 @@ def timed_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, 
         launch = M.demod_plan(ctx, cfg, nstreams, engine=args.engine, nsamples=stride)	# what the library launches
         line = {
             "metric": "audio samples/sec demodulated (whole node), %s-baud 48 kHz f32"
-                      % {"1200": "1200", "rtty": "45.45", "12000": "12000", "same": "520.83"}[name],
+                      % {"1200": "1200", "1200noise": "1200", "rtty": "45.45", "12000": "12000", "same": "520.83"}[name],
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": steps,
             "warmup": warmup, "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
@@ -551,7 +605,7 @@ def timed_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, 
             line["per_rank"] = per_rank
         if world == 1 and cpu_leg:
             # a bounded sample of the same batch on the host cores
-            k = nstreams if name == "1200" else {"rtty": 256, "12000": 1024, "same": 512}[name]
+            k = nstreams if name == "1200" else {"rtty": 256, "12000": 1024, "same": 512, "1200noise": 256}[name]
             k = min(k, nstreams)
             hs = samples[:k].cpu().numpy()
             hl = np.full(k, nsamp, np.int64) if lens is None else lens[:k].cpu().numpy().astype(np.int64)
@@ -661,13 +715,22 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if world > 1:
             dist.init_process_group("gloo", rank=rank, world_size=world)
-        lo, hi = M.shard_range(WORLDLOADS_DEFAULT_STREAMS * world, rank, world)
+        # the job's size exactly as run_workload() derives it (--config, --streams, --scaling)
+        per_gpu = args.streams or WORKLOADS[args.config or "1200"][2]
+        total_streams = per_gpu * 8 if args.scaling == "strong" else per_gpu * world
+        lo, hi = M.shard_range(total_streams, rank, world)
         t = torch.tensor([float(hi - lo)], dtype=torch.float64)
+        table = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            dist.all_gather(table, torch.tensor([lo, hi], dtype=torch.int64))
             dist.barrier()
+        else:
+            table = [torch.tensor([lo, hi], dtype=torch.int64)]
         if rank == 0:
             print(json.dumps({"dry_run": True, "n_gpus": world, "total_streams": int(t.item()),
+                              "scaling": args.scaling, "config": args.config or "1200",
+                              "shards": [[int(a[0]), int(a[1])] for a in table],
                               "launcher": os.environ.get("TORCHELASTIC_RUN_ID", "") != "" or world == 1}))
         if world > 1:
             dist.destroy_process_group()
@@ -692,7 +755,7 @@ def main():
         # the other BASELINE entries at their stated per-GPU sizes, a few timed passes each, device
         # generator, no CPU leg: driver-visible kernel time and roofline fraction per entry
         extra = {}
-        for other in ("12000", "same", "rtty"):		# (shortest kernels first, the 12 ms one last)
+        for other in ("1200noise", "12000", "same", "rtty"):	# (shortest kernels first, the 12 ms one last)
             try:
                 sub = run_workload(other, args, M, torch, dist, ctx, rank, world,
                                    max(1, min(5, args.steps)), 1, cpu_leg=False,

@@ -262,6 +262,129 @@ frame_confidence_fixed( const float2 *mags, uint64_t req_mask, uint64_t req_val 
     return out;
 }
 
+// The same pass written for a wave that runs ALONE and whose time is latency, not throughput:
+// the master of the workgroup engine (mifsk_kernels.hip), whose scoring of a batch is a link of
+// the stream's serial chain.  A wave issues in order; the sequence above, as hipcc schedules it,
+// is one dependent chain after another -- a conditional running sum is an add and a select on
+// the chain, 22 dependent instructions for 11 bits, four such sums one behind the other, then
+// three divisions each inside its own branch, then eleven convert / multiply / convert chains
+// -- and a dependent instruction issues every ~8 cycles where independent ones issue every 2-4.
+// Here the same operations on the same values are laid out in stages whose instructions are
+// independent of one another, pinned with scheduling barriers:
+//   * the per-bit selections first (nothing depends on another bit);
+//   * the four running sums as four chains in lock-step, one ADD per bit on each chain: a
+//     conditional sum `if (c) s += v` is `s += c ? v : 0.0f` -- identical for every value that
+//     can occur (the sums start at +0.0 and every addend is a magnitude, +0.0 or positive or
+//     NaN, so no sum is ever -0.0, and x + 0.0f == x for every other x, NaN included);
+//   * the three quotients without branches (`if (n) s /= n` as `s = n ? s / n : s`: x / 0 is
+//     computed and dropped), so that their sequences interleave;
+//   * the divergence terms stage by stage across the bits (differences, converts, products,
+//     converts back), then the one chain that cannot be avoided: their sum in bit order.
+// Bit for bit the results of frame_confidence_fixed (every parity test runs through it).
+template <int NB>
+__device__ __forceinline__ FrameOut
+frame_confidence_staged( const float2 *mags, uint64_t req_mask, uint64_t req_val )
+{
+    FrameOut out;
+    out.conf = 0.0f;
+    out.ampl = 0.0f;
+    out.bits = 0;
+
+    float2 m[NB];
+#pragma unroll
+    for ( int k = 0; k < NB; k++ )
+	m[k] = mags[k];
+    uint32_t bits = 0;					// NB <= 32 here
+    float sig[NB], nz[NB], mk[NB], sp[NB];
+#pragma unroll
+    for ( int k = 0; k < NB; k++ ) {
+	const bool one = m[k].x > m[k].y;		// fsk.c:161 (strict)
+	sig[k] = one ? m[k].x : m[k].y;
+	const float noise = one ? m[k].y : m[k].x;
+	bits |= ( one ? 1u : 0u ) << k;
+	nz[k] = noise > FLT_EPSILON ? noise : 0.0f;	// fsk.c:279
+	mk[k] = one ? sig[k] : 0.0f;
+	sp[k] = one ? 0.0f : sig[k];
+    }
+    if ( ( (uint64_t)bits ^ req_val ) & req_mask )	// fsk.c:211-212,486-487
+	return out;
+    __builtin_amdgcn_sched_barrier(0);
+    float total_sig = 0.0f, total_noise = 0.0f;
+    float mark_sig = 0.0f, space_sig = 0.0f;
+#pragma unroll
+    for ( int k = 0; k < NB; k++ ) {
+	total_sig += sig[k];				// fsk.c:278
+	total_noise += nz[k];
+	mark_sig += mk[k];
+	space_sig += sp[k];
+	__builtin_amdgcn_sched_barrier(0);
+    }
+    const uint32_t n_mark = (uint32_t)__popc(bits);
+    const uint32_t n_space = (uint32_t)NB - n_mark;
+
+    const float snr = total_sig / total_noise;		// fsk.c:292
+    constexpr double kRcpNB = 1.0 / (double)NB;
+    float avg_sig = div_by_rcp(total_sig, kRcpNB);	// fsk.c:295
+    const float mark_q = mark_sig / (float)n_mark;	// fsk.c:298-301
+    const float space_q = space_sig / (float)n_space;
+    mark_sig = n_mark ? mark_q : mark_sig;
+    space_sig = n_space ? space_q : space_sig;
+
+    const double rc_mark = rcp_of_float(mark_sig), rc_space = rcp_of_float(space_sig);
+    bool odd = ( n_mark && !float_is_plain(mark_sig) ) || ( n_space && !float_is_plain(space_sig) )
+	    || float_is_subnormal(avg_sig);
+    __builtin_amdgcn_sched_barrier(0);
+    float dif[NB];					// fsk.c:305-313
+    double rcs[NB];
+#pragma unroll
+    for ( int k = 0; k < NB; k++ ) {
+	const bool one = ( bits >> k ) & 1u;
+	dif[k] = fabsf(sig[k] - ( one ? mark_sig : space_sig ));
+	rcs[k] = one ? rc_mark : rc_space;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    double prod[NB];
+#pragma unroll
+    for ( int k = 0; k < NB; k++ )
+	prod[k] = (double)dif[k] * rcs[k];
+    __builtin_amdgcn_sched_barrier(0);
+    float term[NB];
+#pragma unroll
+    for ( int k = 0; k < NB; k++ ) {
+	term[k] = (float)prod[k];			// div_by_rcp(dif[k], rcs[k])
+	odd = odd || float_is_subnormal(term[k]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float divergence = 0.0f;
+#pragma unroll
+    for ( int k = 0; k < NB; k++ )
+	divergence += term[k];
+    divergence *= 2.0f;
+    float div_n = div_by_rcp(divergence, kRcpNB);
+    odd = odd || float_is_subnormal(div_n);
+    if ( __any(odd) ) {
+	// (as in frame_confidence_fixed: the divisions proper, for everybody, practically never)
+	avg_sig = total_sig / (float)NB;
+#pragma unroll
+	for ( int k = 0; k < NB; k++ ) {
+	    const float cls = ( bits >> k ) & 1u ? mark_sig : space_sig;
+	    term[k] = fabsf(sig[k] - cls) / cls;
+	}
+	divergence = 0.0f;
+#pragma unroll
+	for ( int k = 0; k < NB; k++ )
+	    divergence += term[k];
+	divergence *= 2.0f;
+	div_n = divergence / (float)NB;
+    }
+    divergence = div_n;
+
+    out.conf = snr * (1.0f - divergence);		// fsk.c:336
+    out.ampl = avg_sig;					// fsk.c:342
+    out.bits = bits;					// fsk.c:439-441
+    return out;
+}
+
 // frame lengths with a specialised confidence pass: start + 8 data + stop with
 // the previous stop bit (11), the 7-bit variant (10); everything else is generic
 __device__ __forceinline__ FrameOut
@@ -274,6 +397,23 @@ frame_confidence_any( const float2 *mags, uint64_t req_mask, uint64_t req_val, u
     if ( n_bits == 8u )					// RTTY "10ddddd1", SAME "dddddddd"
 	return frame_confidence_fixed<8>(mags, req_mask, req_val);
     return frame_confidence(mags, req_mask, req_val, n_bits);
+}
+
+// ... for the lone, latency-bound wave (the workgroup engine's master)
+__device__ __forceinline__ FrameOut
+frame_confidence_any_staged( const float2 *mags, uint64_t req_mask, uint64_t req_val, uint32_t n_bits )
+{
+#ifndef MIFSK_X_NOSTAGED
+    if ( n_bits == 11u )
+	return frame_confidence_staged<11>(mags, req_mask, req_val);
+    if ( n_bits == 10u )
+	return frame_confidence_staged<10>(mags, req_mask, req_val);
+    if ( n_bits == 8u )
+	return frame_confidence_staged<8>(mags, req_mask, req_val);
+    return frame_confidence(mags, req_mask, req_val, n_bits);
+#else
+    return frame_confidence_any(mags, req_mask, req_val, n_bits);
+#endif
 }
 
 // what one fsk_find_frame() returns (fsk.c:504-511)
@@ -317,15 +457,14 @@ struct ZigZag {
 	id = kind & 3u;
     }
     // i-th candidate (0-based, scan order)
+    // (as selects, not branches: per-lane candidate indices diverge, and a divergent branch
+    // costs the wave both sides plus the EXEC bookkeeping)
     __device__ __forceinline__ uint32_t at( uint32_t i ) const
     {
-	if ( i == 0 )
-	    return first;
-	if ( i <= 2 * D ) {
-	    const uint32_t u = ( i + 1 ) >> 1;
-	    return ( i & 1u ) ? first + u * step : first - u * step;
-	}
-	return first + ( i - D ) * step;
+	const bool zig = i <= 2u * D;			// the alternating part: +1, -1, +2, -2, ...
+	const uint32_t u = zig ? ( i + 1u ) >> 1 : i - D;	// (i == 0: u = 0)
+	const uint32_t off = u * step;
+	return ( zig && ( i & 1u ) == 0u ) ? first - off : first + off;
     }
 };
 
@@ -668,6 +807,26 @@ __device__ __forceinline__ void replay_scan_soft( float &xt, float &xpk, float &
 	: [cv] "v"(cv), [av] "v"(av), [k075] "v"(k075)
 	: "scc", "vcc");
 #undef MIFSK_SOFT_STEP
+}
+
+// maximum of v over the wave's 64 lanes (NaN never wins: v_max_f32 returns the other operand),
+// as a DPP reduction: row_shr 1, 2, 3 / 4 / 8 within each row of 16, then row_bcast 15 and 31
+// across the rows; the result is lane 63's.  (A loop of v_readlane + compare + branch over a
+// handful of candidates costs a VALU -> SALU -> branch round trip per candidate.)
+__device__ __forceinline__ float wave_max_f32( float v )
+{
+    const float ninf = -INFINITY;
+#define MIFSK_MAX_DPP(CTRL, RM)											\
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, ninf),			\
+		__builtin_bit_cast(int, v), (CTRL), (RM), 0xf, false)))
+    MIFSK_MAX_DPP(0x111, 0xf);		// row_shr:1
+    MIFSK_MAX_DPP(0x112, 0xf);		// row_shr:2
+    MIFSK_MAX_DPP(0x114, 0xf);		// row_shr:4  (lane k of a row now holds the max of lanes k-7 .. k)
+    MIFSK_MAX_DPP(0x118, 0xf);		// row_shr:8  (lane 15 of each row: the row's max)
+    MIFSK_MAX_DPP(0x142, 0xa);		// row_bcast:15 into rows 1 and 3
+    MIFSK_MAX_DPP(0x143, 0xc);		// row_bcast:31 into rows 2 and 3
+#undef MIFSK_MAX_DPP
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 __device__ __forceinline__ float lane_bcast( float v, uint32_t src )

@@ -174,6 +174,27 @@ void find_frame_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 __device__ __forceinline__ void lds_barrier();
 __device__ __forceinline__ float lane_bcast( float v, uint32_t src );
 
+// A word of LDS that another wave of the workgroup may be writing.  Through a generic
+// pointer hipcc makes a volatile access a system-scope FLAT instruction and waits for
+// vmcnt(0) behind it -- i.e. for every global load the wave has in flight; as a DS access it
+// is one ds_read_b32 / ds_write_b32 (LDS operations of a workgroup are coherent as they are).
+typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32_t;
+__device__ __forceinline__ uint32_t lds_peek( const uint32_t *p ) { return *(lds_vu32_t *)p; }
+__device__ __forceinline__ void lds_poke( uint32_t *p, uint32_t v ) { *(lds_vu32_t *)p = v; }
+
+// A uniform value read ONCE and kept: the empty asm makes it opaque, so the compiler can
+// neither re-load it from the configuration at every use (an s_load and a wait for the scalar
+// cache in the middle of a serial chain) nor fold it -- it stays in a scalar register or in a
+// lane of a spill VGPR (a v_readlane: one cycle).
+template <typename T>
+__device__ __forceinline__ T keep_scalar( T v )
+{
+#ifndef MIFSK_X_NOHOIST
+    asm volatile("" : "+s"(v));
+#endif
+    return v;
+}
+
 // A stream's workgroup is a master wave and NW worker waves (blockDim.x = 64 (NW +
 // 1)): three workers, or two in the Bell-202 instantiation -- configs[1] measured
 // 0.448 ms with two (rounds of 12 frames, batches of 24, 142 VGPRs at three waves
@@ -342,6 +363,10 @@ struct Master {
     uint32_t		hit_base = 0xFFFFFFFFu;	// cursor of the last scan a lattice frame answered
     bool		cnt_on = false;		// work counters wanted (io.d_counters)
     uint32_t		cyc_par = 0, cyc_conf = 0, cyc_wait = 0, cyc_scan_wait = 0;
+    uint32_t		cyc_sf_load = 0, cyc_sf_corr = 0, cyc_sf_score = 0, cyc_sf_sel = 0;	// solo_fine's phases (profile build)
+    // what the steady state reads of the configuration at every batch, read once (keep_scalar)
+    uint32_t		h_la, h_la_magic, h_nbits;
+    uint64_t		h_req_mask, h_req_val;
 
     __device__ __forceinline__ Master( const DevCfg &c, const double *t, const float *xs,
 	    uint32_t n, StreamLds *l, uint32_t cap, uint32_t lf, uint32_t lat_round )
@@ -353,6 +378,11 @@ struct Master {
 	spec = lat_batch;
 	run = cold = pause = 0;
 	spec_floor = 2;
+	h_la = keep_scalar(cfg.lock_advance);
+	h_la_magic = keep_scalar(cfg.la_magic);
+	h_nbits = keep_scalar(cfg.n_bits);
+	h_req_mask = keep_scalar(cfg.req_mask[0]);
+	h_req_val = keep_scalar(cfg.req_val[0]);
 	// frame `lane` of a batch = frame (lane % lat_round) of round (lane / lat_round)
 	conf_idx = lane * cfg.n_bits;
 	if ( cfg.lat_grid && lat_round ) {
@@ -374,8 +404,8 @@ struct Master {
 	if ( !lat_n || p < lat_anchor )
 	    return ~0u;
 	const uint32_t d = p - lat_anchor;
-	const uint32_t e = udiv_magic(d, cfg.lock_advance, cfg.la_magic);
-	return ( e < lat_n && e * cfg.lock_advance == d ) ? e : ~0u;
+	const uint32_t e = udiv_magic(d, h_la, h_la_magic);
+	return ( e < lat_n && e * h_la == d ) ? e : ~0u;
     }
 
     // the slot for the command that the NEXT barrier publishes
@@ -386,7 +416,7 @@ struct Master {
     {
 	if ( anchor >= N )
 	    return 0;
-	const uint32_t left = udiv_magic(N - anchor - 1u, cfg.lock_advance, cfg.la_magic) + 1u;
+	const uint32_t left = udiv_magic(N - anchor - 1u, h_la, h_la_magic) + 1u;
 	return left < lat_batch ? left : lat_batch;
     }
 
@@ -427,7 +457,7 @@ struct Master {
     __device__ __forceinline__ void lattice_advance()
     {
 	const uint32_t anchor = inflight_anchor, frames = inflight_frames, buf = inflight_buf;
-	const uint32_t next = anchor + frames * cfg.lock_advance;
+	const uint32_t next = anchor + frames * h_la;
 	uint32_t nf = lattice_frames_at(next);
 	nf = nf < spec ? nf : spec;
 	publish_lattice(next, nf, buf ^ 1u);
@@ -438,8 +468,7 @@ struct Master {
 	cyc_wait += t_c - t_w;
 	bump(MIFSK_CNT_LATTICE_BATCHES);
 	if ( lane < frames ) {
-	    const FrameOut fo = frame_confidence_any(&lds->mags[buf][conf_idx],
-						     cfg.req_mask[0], cfg.req_val[0], cfg.n_bits);
+	    const FrameOut fo = frame_confidence_any_staged(&lds->mags[buf][conf_idx], h_req_mask, h_req_val, h_nbits);
 	    lds->c_conf[lane] = fo.conf;
 	    lds->c_ampl[lane] = fo.ampl;
 	    lds->c_bits[lane] = fo.bits;
@@ -456,7 +485,7 @@ struct Master {
     __device__ __forceinline__ void give_up()
     {
 	if ( inflight && lane == 0 )	// command number seq - 1 is the batch in flight
-	    *(volatile uint32_t *)&lds->abort = seq;
+	    lds_poke(&lds->abort, seq);
 	inflight = false;
     }
 
@@ -484,7 +513,7 @@ struct Master {
 	    c->row_org = slab_lo;
 	}
 	if ( inflight && lane == 0 )	// command number seq - 1 is the batch in flight
-	    *(volatile uint32_t *)&lds->abort = seq;
+	    lds_poke(&lds->abort, seq);
 	inflight = false;		// the barrier below also retires any batch in flight
 	bump(MIFSK_CNT_BATCHES);
 	bump(MIFSK_CNT_POSITIONS, nq);
@@ -496,7 +525,7 @@ struct Master {
 	const uint32_t t_conf = MIFSK_CLOCK();
 	cyc_par += t_conf - t_par;
 	if ( lane < nq ) {
-	    const FrameOut f = frame_confidence_any(&lds->mags[0][lane * cfg.n_bits],
+	    const FrameOut f = frame_confidence_any_staged(&lds->mags[0][lane * cfg.n_bits],
 						cfg.req_mask[kind], cfg.req_val[kind], cfg.n_bits);
 	    lds->c_conf[lane] = f.conf;
 	    lds->c_ampl[lane] = f.ampl;
@@ -526,10 +555,19 @@ struct Master {
 	const uint32_t nwin = ( zz.J - 1u ) * nb;
 	if ( zz.J < 2u || nwin > 128u || zz.J - 1u > 64u )
 	    return false;
-	// what the candidates read, rounded out to whole float4
+	const uint32_t t_sf0 = MIFSK_CLOCK();
+	// what the candidates read
 	const uint32_t lo = base + first - zz.D * zz.step + cfg.bit_offset[0];
 	const uint32_t hi = base + first + ( zz.U - 1u ) * zz.step + cfg.bit_offset[( nb - 1u ) & 63u] + B;
+#ifndef MIFSK_X_NOSOLO2
+	// The span is staged from `lo` itself (the 16-byte global loads need no alignment): with an
+	// even search step every window then starts an EVEN number of samples into the buffer (bit
+	// offsets are multiples of 4 here) and is read two samples per LDS instruction.
+	const uint32_t org4 = lo;
+	const bool pairs = ( zz.step & 1u ) == 0u;
+#else
 	const uint32_t org4 = lo & ~3u;
+#endif
 	const uint32_t nvec = ( hi - org4 + 3u ) >> 2;
 	if ( hi > N || hi < lo || org4 + 4u * nvec > N || nvec > 128u
 		|| nvec * 16u + nwin * sizeof(float2) > sizeof(lds->mags[0]) )
@@ -551,6 +589,65 @@ struct Master {
 	for ( int gi = 0; gi < ( NQ + 3 ) / 4; gi++ )
 	    tg[gi] = tw_group_load(tw, (uint32_t)gi, lane);
 	wave_lds_sync();
+#ifdef MIFSK_PROFILE
+	asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+	const uint32_t t_sf1 = MIFSK_CLOCK();
+#ifndef MIFSK_X_NOSOLO2
+	{
+	    // ONE pass: lane l sums window l AND window l + 64 (slots without a window shadow a real
+	    // one: every lane must be active for the broadcasts) -- eight independent accumulator
+	    // chains instead of four, which is what a wave running alone needs to keep its f64
+	    // pipe issuing (a dependent v_fmac_f64_dpp comes back after ~30 cycles), and one trip
+	    // through the table, the magnitudes and the loop instead of two.  Same sums, same order.
+	    const uint32_t wA = lane < nwin ? lane : 0u;
+	    const uint32_t wB = lane + 64u < nwin ? lane + 64u : wA;
+	    const uint32_t qA = udiv_magic(wA, nb, cfg.nbits_magic), qB = udiv_magic(wB, nb, cfg.nbits_magic);
+	    // (on a grid of bit lengths bit k starts k B into the frame: no per-lane load from the
+	    // offset table in the middle of the chain)
+	    const bool grid = cfg.lat_grid != 0u;
+	    const uint32_t kA = wA - qA * nb, kB = wB - qB * nb;
+	    const uint32_t oA = grid ? kA * B : cfg.bit_offset[kA & 63u], oB = grid ? kB * B : cfg.bit_offset[kB & 63u];
+	    const float *pA = sbuf + ( base + zz.at(1u + qA) + oA - org4 );
+	    const float *pB = sbuf + ( base + zz.at(1u + qB) + oB - org4 );
+	    double accA[4] = { 0.0, 0.0, 0.0, 0.0 }, accB[4] = { 0.0, 0.0, 0.0, 0.0 };
+	    auto quad_of = [&]( const float *p, int q ) -> float4 {
+		if ( pairs ) {
+		    const float2 a = *reinterpret_cast<const float2 *>(p + 4 * q);
+		    const float2 b = *reinterpret_cast<const float2 *>(p + 4 * q + 2);
+		    return make_float4(a.x, a.y, b.x, b.y);
+		}
+		return make_float4(p[4 * q], p[4 * q + 1], p[4 * q + 2], p[4 * q + 3]);
+	    };
+	    float4 xa = quad_of(pA, 0), xb = quad_of(pB, 0);
+	    dpp_settle();
+#define MIFSK_SOLO2_SAMPLE(J, G, XA, XB) fma4_bcast<J>(accA, G, XA); fma4_bcast<J>(accB, G, XB);
+#define MIFSK_SOLO2_QUAD(Q)									\
+	    if ( (Q) < NQ ) {									\
+		const float4 ca = xa, cb = xb;							\
+		if ( (Q) + 1 < NQ ) {		/* the next quad's reads ahead of this quad's sums */	\
+		    xa = quad_of(pA, (Q) + 1 < NQ ? (Q) + 1 : 0);					\
+		    xb = quad_of(pB, (Q) + 1 < NQ ? (Q) + 1 : 0);					\
+		}										\
+		const TwGroup &G = tg[(Q) / 4 < 3 ? (Q) / 4 : 0];					\
+		MIFSK_SOLO2_SAMPLE(4 * ( (Q) % 4 ) + 0, G, ca.x, cb.x)					\
+		MIFSK_SOLO2_SAMPLE(4 * ( (Q) % 4 ) + 1, G, ca.y, cb.y)					\
+		MIFSK_SOLO2_SAMPLE(4 * ( (Q) % 4 ) + 2, G, ca.z, cb.z)					\
+		MIFSK_SOLO2_SAMPLE(4 * ( (Q) % 4 ) + 3, G, ca.w, cb.w)					\
+	    }
+	    MIFSK_SOLO2_QUAD(0) MIFSK_SOLO2_QUAD(1) MIFSK_SOLO2_QUAD(2) MIFSK_SOLO2_QUAD(3)
+	    MIFSK_SOLO2_QUAD(4) MIFSK_SOLO2_QUAD(5) MIFSK_SOLO2_QUAD(6) MIFSK_SOLO2_QUAD(7)
+	    MIFSK_SOLO2_QUAD(8) MIFSK_SOLO2_QUAD(9) MIFSK_SOLO2_QUAD(10) MIFSK_SOLO2_QUAD(11)
+#undef MIFSK_SOLO2_QUAD
+#undef MIFSK_SOLO2_SAMPLE
+	    if ( lane < nwin )
+		sm[lane] = make_float2(band_mag(accA[0], accA[1], cfg.magscalar),
+				       band_mag(accA[2], accA[3], cfg.magscalar));
+	    if ( lane + 64u < nwin )
+		sm[lane + 64u] = make_float2(band_mag(accB[0], accB[1], cfg.magscalar),
+					     band_mag(accB[2], accB[3], cfg.magscalar));
+	}
+#else
 	for ( uint32_t w0 = 0; w0 < nwin; w0 += 64u ) {
 	    const uint32_t w = w0 + lane;
 	    const bool active = w < nwin;
@@ -578,25 +675,29 @@ struct Master {
 		sm[w] = make_float2(band_mag(acc[0], acc[1], cfg.magscalar),
 				    band_mag(acc[2], acc[3], cfg.magscalar));
 	}
+#endif
 	wave_lds_sync();
+	const uint32_t t_sf2 = MIFSK_CLOCK();
 	FrameOut f;
 	f.conf = 0.0f; f.ampl = 0.0f; f.bits = 0;
 	if ( lane < zz.J - 1u )
-	    f = frame_confidence_any(&sm[lane * nb], cfg.req_mask[0], cfg.req_val[0], nb);
+	    f = frame_confidence_any_staged(&sm[lane * nb], cfg.req_mask[0], cfg.req_val[0], nb);
 	bump(MIFSK_CNT_POSITIONS, zz.J - 1u);
+	const uint32_t t_sf3 = MIFSK_CLOCK();
 	// fsk.c:492-501 in scan order, candidate 0 first; the limit of this scan
 	// is INFINITY (minimodem.c:1367)
+	// -- i.e. the FIRST candidate, in scan order, that attains the maximum of the candidates'
+	// confidences wins if that maximum exceeds candidate 0's (strict >, a NaN never wins, and
+	// after an infinite confidence nothing can): lane i - 1 holds candidate i
 	r = c0;
 	uint32_t win = 0;
-	if ( !( r.conf >= INFINITY ) ) {
-	    for ( uint32_t i = 1; i < zz.J; i++ ) {
-		const float c = lane_bcast(f.conf, i - 1u);
-		if ( r.conf < c ) {
-		    r.conf = c;
-		    win = i;
-		    if ( r.conf >= INFINITY )
-			break;
-		}
+	{
+	    const bool cand = lane < zz.J - 1u && f.conf == f.conf;
+	    const float best = wave_max_f32(cand ? f.conf : -INFINITY);
+	    if ( r.conf < best ) {
+		const unsigned long long at = __ballot(cand && f.conf == best);
+		win = (uint32_t)__ffsll((long long)at);		// 1 + the first such lane = its candidate index
+		r.conf = best;
 	    }
 	}
 	if ( win ) {
@@ -606,6 +707,10 @@ struct Master {
 	    r.bits = ( (uint64_t)bhi << 32 ) | blo;
 	    r.start = zz.at(win);
 	}
+	cyc_sf_load += t_sf1 - t_sf0;
+	cyc_sf_corr += t_sf2 - t_sf1;
+	cyc_sf_score += t_sf3 - t_sf2;
+	cyc_sf_sel += MIFSK_CLOCK() - t_sf3;
 	return true;
     }
 
@@ -756,6 +861,22 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
     const bool t0 = lane == 0;
 
     Master<USE_SLAB> ctx(cfg, tw, x, N, lds, slab_cap, lat_frames, lat_round);
+    // What the bulk path below reads of the configuration for every batch of lattice frames,
+    // read once (keep_scalar): left as cfg.x the compiler re-loads each at every use -- a dozen
+    // s_load + s_waitcnt round trips through the scalar cache per batch, in the one wave whose
+    // serial chain paces the workgroup.
+    const uint32_t h_first1 = keep_scalar(cfg.try_first[1]);
+    const uint32_t h_expect = keep_scalar(cfg.expect_nsamples);
+    const uint32_t h_fn = keep_scalar(cfg.frame_nsamples);
+    const uint32_t h_overscan = keep_scalar(cfg.overscan);
+    const float h_limit = keep_scalar(cfg.search_limit);
+    const float h_thr = keep_scalar(cfg.conf_threshold);
+    // data_bits_of() (minimodem.c:1415-1428) as one shift and one mask
+    const uint32_t h_dshift = keep_scalar(( cfg.has_stopbits ? 1u : 0u ) + cfg.nstartbits);
+    const uint64_t h_dmask = keep_scalar(cfg.n_data_bits >= 64u ? ~0ULL : ( 1ULL << cfg.n_data_bits ) - 1ULL);
+    const bool h_msb = cfg.msb_first != 0u;
+    const bool h_rx_sync = cfg.do_rx_sync != 0u;
+    const uint64_t h_sync_byte = keep_scalar(cfg.sync_byte);
     // LINEAR rounds are cheap (coalesced staging, short windows): never speculate
     // less than one round; DIRECT rounds stream whole windows per lane
     if ( lat_mode == LAT_LINEAR )
@@ -863,7 +984,7 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 	// ------------------------------------------------------------------
 	if ( carrier && advance && ( ST ? ( base <= N_lat && advance <= N_lat - base ) : advance <= N - base ) ) {
 	    const uint32_t t_bulk = MIFSK_CLOCK();
-	    const uint32_t first = cfg.try_first[1];
+	    const uint32_t first = h_first1;
 	    const uint32_t nb = base + advance;		// cursor of the next iteration
 	    const uint32_t p = nb + first;
 	    const uint32_t e0 = ctx.lattice_lookup(p);
@@ -871,10 +992,10 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 	    if ( e0 != ~0u ) {
 		uint32_t K = ctx.lat_n - e0;
 		// frame k sits at cursor nb + k*lock_advance and needs expect_nsamples from there
-		const uint32_t fn = cfg.frame_nsamples;
-		const uint32_t la = cfg.lock_advance;
-		const uint32_t room = N_lat - nb >= cfg.expect_nsamples
-				    ? udiv_magic(N_lat - nb - cfg.expect_nsamples, la, cfg.la_magic) + 1u : 0u;
+		const uint32_t fn = h_fn;
+		const uint32_t la = ctx.h_la;
+		const uint32_t room = N_lat - nb >= h_expect
+				    ? udiv_magic(N_lat - nb - h_expect, la, ctx.h_la_magic) + 1u : 0u;
 		K = K < room ? K : room;
 		// this lane's candidate (lane k <-> entry e0 + k)
 		const bool have = lane < K;
@@ -902,10 +1023,10 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 		cyc_dpp += MIFSK_CLOCK() - t_dpp;
 		const float t = xt, pk = xpk, sc = xsc, sa = xsa;	// state after frame `lane`
 		const bool ok = have
-		    && cv > 0.0f && cv >= cfg.search_limit	// fsk.c:492,499: first try ends the scan
+		    && cv > 0.0f && cv >= h_limit		// fsk.c:492,499: first try ends the scan
 		    && !( cv < my_pk * 0.75f )			// minimodem.c:1278
 		    && !( av < my_t * 0.25f )			// minimodem.c:1286
-		    && !( cv <= cfg.conf_threshold );		// minimodem.c:1292
+		    && !( cv <= h_thr );			// minimodem.c:1292
 		const unsigned long long bad = __ballot(have && !ok);
 		const uint32_t n = bad ? (uint32_t)__ffsll((long long)bad) - 1u : K;
 		float track, peak, ctot, atot;
@@ -942,8 +1063,10 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 		    uint64_t db = 0;
 		    bool suppressed = false;
 		    if ( mine ) {
-			db = data_bits_of(cfg, lds->c_bits[e0 + lane]);
-			suppressed = cfg.do_rx_sync && db == cfg.sync_byte;
+			db = ( lds->c_bits[e0 + lane] >> h_dshift ) & h_dmask;	// data_bits_of()
+			if ( h_msb )
+			    db = bit_reverse(db, cfg.n_data_bits);
+			suppressed = h_rx_sync && db == h_sync_byte;
 		    }
 		    const unsigned long long keep = __ballot(mine && !suppressed);
 
@@ -981,7 +1104,7 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 		    amplitude_total = atot;
 		    nframes_decoded += n;
 		    noconfidence = 0;
-		    carrier_nsamples += (uint64_t)n * ( fn + first - cfg.overscan );
+		    carrier_nsamples += (uint64_t)n * ( fn + first - h_overscan );
 		    base = nb + ( n - 1u ) * la;
 		    advance = la;
 		    if constexpr ( ST ) {
@@ -1179,7 +1302,7 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 	// iteration will search first, unless a matching batch is already in
 	// flight or already scored
 	if ( ctx.lat_batch && advance <= N - base ) {
-	    const uint32_t p = base + advance + cfg.try_first[1];
+	    const uint32_t p = base + advance + h_first1;
 	    const bool cached = ctx.lattice_lookup(p) != ~0u;
 	    const uint32_t t_ls = MIFSK_CLOCK();
 	    if ( ctx.pause ) {
@@ -1267,11 +1390,12 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 	    c[MIFSK_CNT_CYC_CONFIDENCE] = ctx.cyc_conf;
 	    c[MIFSK_CNT_CYC_BULK] = cyc_bulk;
 	    c[16] = cyc_general;	// general iterations that produced a frame (profile build)
-	    c[17] = cyc_restart;
-	    c[18] = cyc_s1;
-	    c[19] = cyc_s2;
+	    // (profile build: solo_fine's phases ride in the high words)
+	    c[17] = cyc_restart | ( (uint64_t)ctx.cyc_sf_load << 32 );
+	    c[18] = cyc_s1 | ( (uint64_t)ctx.cyc_sf_corr << 32 );
+	    c[19] = cyc_s2 | ( (uint64_t)ctx.cyc_sf_score << 32 );
 	    c[20] = cyc_dpp;
-	    c[21] = ctx.cyc_scan_wait;
+	    c[21] = ctx.cyc_scan_wait | ( (uint64_t)ctx.cyc_sf_sel << 32 );
 #ifdef MIFSK_PROFILE
 	    // when this stream started and ended on the chip-wide 100 MHz clock
 	    c[23] = ( wall_clock64() & 0xFFFFFFFFull ) | ( (uint64_t)t_wall0 << 32 );
@@ -1286,30 +1410,40 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 }
 
 
+// what a worker reads of the configuration in every round, read once per kernel (keep_scalar),
+// and of the command, read once per command: each used to be an s_load / ds_read round trip
+// with its wait at the top of every round
+struct WorkerHot {
+    uint32_t	n_bits, B, la;
+    bool	grid;
+    float	magscalar;
+    uint32_t	buf, total, anchor0;	// the LATTICE command being worked on
+};
+
 template <int NQ>
-__device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const double *__restrict__ tw,
-	StreamLds *lds, const StreamLds::Cmd *cmd, const float *__restrict__ x, uint32_t N,
+__device__ __forceinline__ void worker_lattice_linear( const WorkerHot &h, const double *__restrict__ tw,
+	StreamLds *lds, const float *__restrict__ x, uint32_t N,
 	uint32_t region_floats, uint32_t lat_frames, uint32_t wkr, uint32_t done, uint32_t win_base,
 	uint32_t rel_lane, uint32_t safe_limit,
 	float4 (&pbuf)[STAGE_VEC], uint32_t &pref_org4, uint32_t (&wcyc)[6], const TwGroup (&tgr)[3] )
 {
     uint32_t lane = threadIdx.x & 63u;
     asm volatile("" : "+v"(lane));	// per-round values derived from it are recomputed, not spilled
-    const uint32_t n_bits = cfg.n_bits, B = cfg.bit_nsamples;
-    if ( cfg.lat_grid )
+    const uint32_t n_bits = h.n_bits, B = h.B;
+    if ( h.grid )
 	rel_lane = ( wkr * 64u + lane ) * B;	// (one multiply: cheaper than keeping it live)
-    const uint32_t buf = cmd->buf;
+    const uint32_t buf = h.buf;
     float *region = lds->slab + (size_t)wkr * region_floats;
     // A batch is scored by the master in one go but correlated here in ROUNDS
     // of lat_frames frames (what the regions hold); the lattice simply
     // continues from one round into the next, and so does the prefetch.
-    const uint32_t total = cmd->frames;
+    const uint32_t total = h.total;
     {
 	const uint32_t t_in = MIFSK_CLOCK();
 	const uint32_t frames = total - done < lat_frames ? total - done : lat_frames;
-	const uint32_t anchor = cmd->anchor + done * cfg.lock_advance;
+	const uint32_t anchor = h.anchor0 + done * h.la;
 	// distinct windows of the round (cfg.lat_grid: consecutive frames share one)
-	const uint32_t nwin = cfg.lat_grid ? frames * ( n_bits - 1u ) + 1u : frames * n_bits;
+	const uint32_t nwin = h.grid ? frames * ( n_bits - 1u ) + 1u : frames * n_bits;
 	const uint32_t w = wkr * 64u + lane;
 	if ( wkr * 64u >= nwin ) {
 	    pref_org4 = 0xFFFFFFFFu;
@@ -1392,7 +1526,7 @@ __device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const 
 	// and with one round of look-ahead the memory system already delivers
 	// 6.1 TB/s to this access pattern: profiles/r04_history.md.)
 	{
-	    const uint32_t nlo = lo + lat_frames * cfg.lock_advance;
+	    const uint32_t nlo = lo + lat_frames * h.la;
 	    const bool ok = nlo >= lo && nlo <= safe_limit - kRoundFloats;
 	    const float *pb = x + ( ok ? nlo : 0u ) + ( lane << 2 );
 #pragma unroll
@@ -1427,8 +1561,8 @@ __device__ __forceinline__ void worker_lattice_linear( const DevCfg &cfg, const 
 	    mr = acc[0]; mi = acc[1]; sr = acc[2]; si = acc[3];
 	}
 	if ( active )
-	    lds->mags[buf][win_base + w] = make_float2(band_mag(mr, mi, cfg.magscalar),
-							   band_mag(sr, si, cfg.magscalar));
+	    lds->mags[buf][win_base + w] = make_float2(band_mag(mr, mi, h.magscalar),
+							   band_mag(sr, si, h.magscalar));
 	wave_lds_sync();			// the region is rewritten by the next round
 	const uint32_t t_out = MIFSK_CLOCK();
 	wcyc[0] += t_mid - t_in;
@@ -1528,6 +1662,13 @@ __device__ __forceinline__ void worker_main( const DevCfg *__restrict__ cfgp,
     }
     uint32_t pref_org4 = 0xFFFFFFFFu;
     uint32_t wcyc[6] = { 0, 0, 0, 0, 0, 0 };
+    WorkerHot hot;
+    hot.n_bits = keep_scalar(cfg.n_bits);
+    hot.B = keep_scalar(cfg.bit_nsamples);
+    hot.la = keep_scalar(cfg.lock_advance);
+    hot.grid = cfg.lat_grid != 0u;
+    hot.magscalar = keep_scalar(cfg.magscalar);
+    hot.buf = hot.total = hot.anchor0 = 0u;
     for ( uint32_t seq = 0; ; seq++ ) {
 	const uint32_t t_b = MIFSK_CLOCK();
 	lds_barrier();			// command number `seq` has been published
@@ -1548,20 +1689,23 @@ __device__ __forceinline__ void worker_main( const DevCfg *__restrict__ cfgp,
 	    if ( lat_mode == LAT_LINEAR ) {
 		// rounds of lat_frames frames (what the regions hold)
 		const uint32_t total = cmd->frames;
+		hot.total = keep_scalar((uint32_t)__builtin_amdgcn_readfirstlane((int)total));
+		hot.buf = keep_scalar((uint32_t)__builtin_amdgcn_readfirstlane((int)cmd->buf));
+		hot.anchor0 = keep_scalar((uint32_t)__builtin_amdgcn_readfirstlane((int)cmd->anchor));
 		uint32_t win_base = 0;
 		for ( uint32_t done = 0; done < total; done += lat_frames, win_base += wins_per_round ) {
 		    // given up by the master (the lattice broke in the batch before):
 		    // the issue slots are better spent by the other workgroups' waves
-		    if ( *(volatile uint32_t *)&lds->abort == seq + 1u )
+		    if ( lds_peek(&lds->abort) == seq + 1u )
 			break;
-		    worker_lattice_linear<NQ>(cfg, tw, lds, cmd, x, N, region_floats, lat_frames,
+		    worker_lattice_linear<NQ>(hot, tw, lds, x, N, region_floats, lat_frames,
 					  wkr, done, win_base, rel_lane, safe_limit, pbuf, pref_org4, wcyc, tgr);
 		}
 	    } else if constexpr ( NQ == 0 ) {	// (an instantiation for one bit length is linear by construction)
 		const uint32_t total = cmd->frames;
 		uint32_t win_base = 0;
 		for ( uint32_t done = 0; done < total; done += lat_frames, win_base += wins_per_round ) {
-		    if ( *(volatile uint32_t *)&lds->abort == seq + 1u )
+		    if ( lds_peek(&lds->abort) == seq + 1u )
 			break;
 		    worker_lattice_direct(cfg, tw, lds, cmd, x, N, lat_frames, wkr, done, win_base, wcyc);
 		}

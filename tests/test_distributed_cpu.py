@@ -216,3 +216,126 @@ def test_bench_spawns_its_own_ranks_when_no_launcher_is_around():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["dry_run"] and d["n_gpus"] == 2 and d["total_streams"] == 2048
+
+
+def _world8_worker(rank, world, port, q):
+    """bench.py's timed loop at the size of the node it is written for: EIGHT ranks, unequal
+    shards (1027 streams: 129 129 129 128 ...), the narrow gather (`cols`), double-buffered
+    outputs with the gather of step i overlapped with step i + 1, the root fanning in from
+    seven peers at once -- and one rank that fails in the middle of the loop, which must end
+    in RankFailed on every rank (agree()) after every gather has still been joined."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        total, cap, cols, steps = 1027, 24, 9, 6
+        spans = [M.shard_range(total, r, world) for r in range(world)]
+        rows = [b - a for a, b in spans]
+        lo, hi = spans[rank]
+        g = M.ByteGatherer(dist, rank, world, cols=cols, rows=rows)
+        bufs = [(torch.zeros((rows[rank], cap), dtype=torch.uint8), torch.zeros(rows[rank], dtype=torch.int32))
+                for _ in range(2)]
+        pending = [None, None]
+        failure = None
+        checked = 0
+
+        def decode(step, b):
+            # "stream gid decoded at step `step`": byte j of stream gid = (gid + 3 j + step) mod 251
+            gid = torch.arange(lo, hi, dtype=torch.int64).reshape(-1, 1)
+            j = torch.arange(cap, dtype=torch.int64).reshape(1, -1)
+            bufs[b][0].copy_(((gid + 3 * j + step) % 251).to(torch.uint8))
+            bufs[b][1].copy_(((torch.arange(lo, hi) + step) % (cols + 1)).to(torch.int32))
+
+        def check(step):
+            # what the root holds of every peer after step `step`'s gather has been waited on
+            n = 0
+            for r in range(1, world):
+                rb, rn = g.received(r)
+                plo, phi = spans[r]
+                assert tuple(rb.shape) == (phi - plo, cols) and tuple(rn.shape) == (phi - plo,)
+                gid = torch.arange(plo, phi, dtype=torch.int64).reshape(-1, 1)
+                j = torch.arange(cols, dtype=torch.int64).reshape(1, -1)
+                assert torch.equal(rb, ((gid + 3 * j + step) % 251).to(torch.uint8)), (r, step)
+                assert torch.equal(rn, ((torch.arange(plo, phi) + step) % (cols + 1)).to(torch.int32)), (r, step)
+                n += phi - plo
+            return n
+
+        for step in range(steps):
+            b = step & 1
+            if pending[b] is not None:
+                for w in pending[b]:
+                    w.wait()
+                pending[b] = None
+                if rank == 0:
+                    checked += check(step - 2)
+            try:
+                if rank == 5 and step == 3:
+                    raise RuntimeError("launch failed on rank 5")
+                decode(step, b)
+            except Exception as e:				# noqa: BLE001 -- this rank still joins every gather
+                failure = failure or e
+            pending[b] = g.start(*bufs[b])
+        for b in ((steps) & 1, (steps + 1) & 1):		# oldest first
+            if pending[b] is not None:
+                for w in pending[b]:
+                    w.wait()
+                pending[b] = None
+        dist.barrier()
+        verdict = "ok"
+        try:
+            bench.agree(torch, dist, failure, "timed loop")
+        except bench.RankFailed as e:
+            verdict = "failed:" + ("mine" if "rank 5" in str(e) else "peer")
+        q.put((rank, rows, checked, verdict, g.bytes_per_peer(rows[rank])))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_ranks_pipelined_narrow_gather_unequal_shards_one_failing_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 8
+    procs = [ctx.Process(target=_world8_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        rank, rows, checked, verdict, bpp = q.get(timeout=300)
+        got[rank] = (rows, checked, verdict, bpp)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    rows = got[0][0]
+    assert rows == [129, 129, 129, 128, 128, 128, 128, 128] and sum(rows) == 1027
+    # the root verified every peer's rows of four completed gathers (steps 0..3) inside the loop
+    assert got[0][1] == 4 * (1027 - 129)
+    for r in range(world):
+        assert got[r][2] == ("failed:mine" if r == 5 else "failed:peer"), (r, got[r][2])
+        assert got[r][3] == rows[r] * 9 + 4 * rows[r]
+
+
+def test_bench_dry_run_eight_ranks_strong_scaling_configs3():
+    """`bench.py --gpus 8 --scaling strong --config 12000` through its own launcher, without a
+    GPU: the job is BASELINE configs[3]'s 65536 streams whatever the rank count, the shards are
+    contiguous and cover it exactly."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env["MIFSK_BENCH_DRYRUN"] = "1"
+    env["OMP_NUM_THREADS"] = "1"
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--scaling", "strong",
+                        "--config", "12000"], env=env, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["dry_run"] and d["n_gpus"] == 8 and d["total_streams"] == 65536 and d["scaling"] == "strong"
+    assert d["shards"] == [[8192 * i, 8192 * (i + 1)] for i in range(8)]

@@ -42,7 +42,7 @@ def _run(M, torch, ctx, cfg, host, want=("bytes", "episodes")):
     return M.results_to_host(out)
 
 
-def test_config2_bell202_1024_streams_x_10s(gpu):
+def test_configs1_bell202_1024_streams_x_10s(gpu):
     """BASELINE configs[1]: 1024 streams x 480000 samples, 1200 baud."""
     M, torch, ctx = gpu
     cfg = M.rx_config("1200")
@@ -63,7 +63,44 @@ def test_config2_bell202_1024_streams_x_10s(gpu):
     _assert_all_streams_equal_oracle(res, host, None, O.oracle_config("1200"))
 
 
-def test_config4_12000_baud_8192_streams(gpu):
+def test_configs1_bell202_under_the_references_impairments(gpu):
+    """configs[1]'s batch (1024 streams x 480000 samples) under what the reference's own noise tests
+    apply at 1200 baud (tests/40-noise.test:14-20): clean, AWGN at 20 / 12 / 9 / 6 dB, DC offset
+    0.05 / 0.10 / 0.50, interleaved -- the conditions of bench.py's "1200noise" entry.  The
+    workgroup engine speculates on the lock holding; here it breaks all the time.  Every stream
+    equals the oracle frame for frame on the identical buffer, whether or not the payload survives;
+    the clean, 20 dB and DC-offset streams must decode their payload."""
+    M, torch, ctx = gpu
+    cfg = M.rx_config("1200")
+    host, payloads = _batch(M, cfg, 1024, 1199, seed=43, nsamples=480000)
+    conds = [("snr", None), ("snr", 20), ("snr", 12), ("snr", 9), ("snr", 6), ("dc", 0.05), ("dc", 0.10), ("dc", 0.50)]
+    nc = len(conds)
+    x = torch.from_numpy(host).cuda()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(12)
+    for k, (kind, v) in enumerate(conds):
+        rows = x[k::nc]
+        if kind == "snr" and v is not None:
+            sigma = float(np.sqrt(0.5 / 10 ** (v / 10)))
+            rows += torch.randn(rows.shape, generator=g, device="cuda", dtype=torch.float32) * sigma
+        elif kind == "dc":
+            rows -= np.float32(v)
+    for engine in (None, "wave"):
+        out = M.demod_batch(ctx, cfg, x, want=("bytes", "frames", "episodes"), episodes_cap=64, engine=engine)
+        torch.cuda.synchronize()
+        res = M.results_to_host(out)
+        ok = {k: 0 for k in range(nc)}
+        for i in range(1024):
+            nb = int(res["nbytes"][i])
+            ok[i % nc] += payloads[i].tobytes() in res["bytes"][i, :nb].tobytes()
+        assert all(ok[k] == 128 for k in (0, 1, 5, 6, 7)), ok
+        by_cond = _assert_all_streams_equal_oracle(res, x, None, O.oracle_config("1200"), groups=lambda i: i % nc)
+        assert all(v == [128, 128] for v in by_cond.values()), by_cond
+    del x, out
+    torch.cuda.empty_cache()
+
+
+def test_configs3_12000_baud_8192_streams(gpu):
     """BASELINE configs[3], one GPU's shard: 8192 streams x 2 s at 12000 baud."""
     M, torch, ctx = gpu
     cfg = M.rx_config("12000")
@@ -111,7 +148,7 @@ def _assert_all_streams_equal_oracle(res, x, n, ocfg, groups=None):
     return by_group
 
 
-def test_config3_rtty_4096_streams_x_30s(gpu):
+def test_configs2_rtty_4096_streams_x_30s(gpu):
     """BASELINE configs[2] at its stated size: RTTY 45.45 baud (1056-sample bit windows),
     4096 streams x 30 s = 23.6 GB resident.  Every stream's 5-bit words must come back as
     transmitted and every stream equals the oracle frame for frame (the samples cross PCIe in
@@ -131,11 +168,11 @@ def test_config3_rtty_4096_streams_x_30s(gpu):
     torch.cuda.empty_cache()
 
 
-def test_config5_same_8192_streams_x_10s_noise_sweep(gpu):
+def test_configs4_same_8192_streams_x_10s_noise_sweep(gpu):
     """BASELINE configs[4] at one GPU's size: NOAA SAME, 8192 streams x 10 s, amplitude 0.5,
-    AWGN at SNR inf / 20 / 12 / 9 / 6 / 3 dB plus the reference's DC-offset sweep
-    (tests/40-noise.test), conditions interleaved over the batch.  All 8192 streams (1024 per
-    condition) are compared frame for frame with the oracle on identical buffers -- whether
+    AWGN at SNR inf / 20 / 12 / 9 / 6 / 3 dB plus the reference's DC-offset sweep 0.05 / 0.10 /
+    0.50 (tests/40-noise.test:20), conditions interleaved over the batch.  All 8192 streams (910
+    or 911 per condition) are compared frame for frame with the oracle on identical buffers -- whether
     or not the payload survives the noise -- and the clean and DC-offset streams must decode
     their payload."""
     M, torch, ctx = gpu
@@ -147,11 +184,14 @@ def test_config5_same_8192_streams_x_10s_noise_sweep(gpu):
     x, n, words = _device_batch(M, torch, ctx, cfg, 8192, 10.0, seed=5, lo=32, hi=127, amplitude=0.5,
                                 max_lead=0)
     p_sig = 0.5 ** 2 / 2
-    conds = [("snr", None), ("snr", 20), ("snr", 12), ("snr", 9), ("snr", 6), ("snr", 3), ("dc", 0.05), ("dc", 0.50)]
+    conds = [("snr", None), ("snr", 20), ("snr", 12), ("snr", 9), ("snr", 6), ("snr", 3),
+             ("dc", 0.05), ("dc", 0.10), ("dc", 0.50)]
+    nc = len(conds)
+    per = [len(range(k, 8192, nc)) for k in range(nc)]
     g = torch.Generator(device="cuda")
     g.manual_seed(11)
     for k, (kind, v) in enumerate(conds):
-        rows = x[k::8]
+        rows = x[k::nc]
         if kind == "snr" and v is not None:
             sigma = float(np.sqrt(p_sig / 10 ** (v / 10)))
             rows += torch.randn(rows.shape, generator=g, device="cuda", dtype=torch.float32) * sigma
@@ -160,13 +200,13 @@ def test_config5_same_8192_streams_x_10s_noise_sweep(gpu):
     out = M.demod_batch(ctx, cfg, x, nsamples=n, want=("bytes", "frames", "episodes"), episodes_cap=64)
     torch.cuda.synchronize()
     res = M.results_to_host(out)
-    ok = {k: 0 for k in range(8)}
+    ok = {k: 0 for k in range(nc)}
     for i in range(8192):
         nb = int(res["nbytes"][i])
-        ok[i % 8] += words[i].tobytes() in res["bytes"][i, :nb].tobytes()
-    assert ok[0] == 1024 and ok[6] == 1024 and ok[7] == 1024, ok
-    assert ok[1] >= 800 and ok[5] <= ok[1], ok          # 20 dB mostly decodes; 3 dB does no better
-    by_cond = _assert_all_streams_equal_oracle(res, x, n, O.oracle_config("same"), groups=lambda i: i % 8)
-    assert all(v == [1024, 1024] for v in by_cond.values()), by_cond
+        ok[i % nc] += words[i].tobytes() in res["bytes"][i, :nb].tobytes()
+    assert ok[0] == per[0] and ok[6] == per[6] and ok[7] == per[7] and ok[8] == per[8], ok
+    assert ok[1] >= 0.78 * per[1] and ok[5] <= ok[1], ok          # 20 dB mostly decodes; 3 dB does no better
+    by_cond = _assert_all_streams_equal_oracle(res, x, n, O.oracle_config("same"), groups=lambda i: i % nc)
+    assert all(v == [per[k], per[k]] for k, v in by_cond.items()), by_cond
     del x, out
     torch.cuda.empty_cache()

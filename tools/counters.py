@@ -24,19 +24,8 @@ def main():
     entry, mode, per_gpu, seconds, _, amplitude = bench.WORKLOADS[args.config]
     n = args.streams or per_gpu
     cfg = M.rx_config(mode)
-    if args.config == "1200":
-        host = np.zeros((n, bench.NSAMPLES), np.float32)
-        for i in range(n):
-            x, _ = bench.make_stream(M, cfg, i)
-            host[i, :len(x)] = x
-        d, lens = torch.from_numpy(host).cuda(), None
-    else:
-        nsamp = int(seconds * cfg.sample_rate)
-        wl = [bench.stream_words(args.config, cfg, i, nsamp) for i in range(n)]
-        words = torch.from_numpy(np.stack([w for w, _ in wl])).cuda()
-        lead = torch.tensor([l for _, l in wl], dtype=torch.int32).cuda()
-        d, lens = M.synthesize_batch(ctx, cfg, words, stride=(nsamp + 3) & ~3, leading_silence=lead,
-                                     amplitude=amplitude)
+    nsamp = bench.NSAMPLES if args.config in ("1200", "1200noise") else int(seconds * cfg.sample_rate)
+    d, lens = bench.make_batch(args.config, M, torch, ctx, cfg, 0, 0, n, nsamp, (nsamp + 3) & ~3, amplitude, [None] * n)
     for _ in range(2):
         out = M.demod_batch(ctx, cfg, d, nsamples=lens, want=("bytes", "counters"), engine=args.engine)
     torch.cuda.synchronize()
@@ -49,7 +38,8 @@ def main():
     # the worker's three counters carry the staging phase's parts in their high words
     # (profile build, linear rounds): wait for the round's samples / registers -> LDS /
     # issue of the next round's loads
-    hi = {13: "w_stage_wait", 14: "w_stage_write", 15: "w_stage_issue"}
+    hi = {13: "w_stage_wait", 14: "w_stage_write", 15: "w_stage_issue",
+          17: "solo_fine_load", 18: "solo_fine_correlate", 19: "solo_fine_score", 21: "solo_fine_select"}
     hiv = {k: (raw0[:, k] >> np.uint64(32)).astype(np.float64) for k in hi}
     c = (raw0 & np.uint64(0xFFFFFFFF)).astype(np.float64)
     for k in range(c.shape[1]):
