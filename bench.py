@@ -623,6 +623,8 @@ def timed_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, 
         if world == 1 and name == "1200" and not args.no_h2d:
             line["h2d_inclusive"] = h2d_inclusive(M, torch, ctx, cfg, samples, nsamp, frames_cap, gpu_bytes,
                                                   gpu_nbytes)
+        if world == 1 and name == "1200" and cpu_leg:
+            line["legacy_dropin"] = legacy_dropin(samples, nsamp, int(cfg.sample_rate))
     del samples, bufs
     torch.cuda.empty_cache()
     return line
@@ -661,6 +663,49 @@ def h2d_inclusive(M, torch, ctx, cfg, samples, nsamp, frames_cap, gpu_bytes, gpu
             M.host_free(host)
         except Exception as e:					# noqa: BLE001 -- a diagnostic leg must not kill the line
             out[fmt] = {"error": repr(e)}
+    return out
+
+
+def legacy_dropin(samples, nsamp, sample_rate):
+    """What INTEGRATION.md section 1 costs: the reference's unmodified main() over the five legacy
+    fsk_* symbols (oracle/_ref/minimodem_mifsk: one H2D + launch + D2H per fsk_find_frame call),
+    next to the same main() with integration/minimodem-rx-batch.patch (oracle/_ref/
+    minimodem_mifsk_rxbatch: the file as a batch of one), on ONE stream of configs[1] read from a
+    WAV file -- process start, file read and context creation included in both.  Never `value`."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as O
+    out = {"unit": "samples/s", "sample": "stream 0 of the batch (%d samples) as a float32 WAV, one process, wall clock" % nsamp}
+    tmp = tempfile.mkdtemp(prefix="mifsk-legacy-")
+    path = os.path.join(tmp, "s0.wav")
+    try:
+        write_wav_f32(path, samples[0, :nsamp].cpu().numpy(), sample_rate)
+        texts = {}
+        for key, exe in (("five_legacy_symbols", os.path.join(O.REF_DIR, "minimodem_mifsk")),
+                         ("rx_batch_patch", os.path.join(O.REF_DIR, "minimodem_mifsk_rxbatch")),
+                         ("reference_cpu", O.MINIMODEM_REF)):
+            if not os.path.exists(exe):
+                out[key] = {"error": "not built"}
+                continue
+            best = None
+            for _ in range(2):
+                t0 = time.perf_counter()
+                r = subprocess.run([exe, "--rx", "--quiet", "--file", path, "1200"],
+                                   stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            texts[key] = r.stdout
+            out[key] = {"value": nsamp / best, "seconds": best, "returncode": r.returncode}
+        if len(texts) > 1:
+            ref = texts.get("reference_cpu", next(iter(texts.values())))
+            out["outputs_identical"] = all(t == ref for t in texts.values())
+    except Exception as e:					# noqa: BLE001 -- a diagnostic leg must not kill the line
+        out["error"] = repr(e)
+    finally:
+        try:
+            os.unlink(path)
+            os.rmdir(tmp)
+        except OSError:
+            pass
     return out
 
 

@@ -373,8 +373,12 @@ class ByteGatherer:
     (bench.py): start(bytes, nbytes) posts one grouped send/recv -- every peer
     sends on its own link to the root (RCCL over xGMI on GPUs, gloo in the CPU
     tests) -- and returns the work handles; the caller waits on them before it
-    reuses the buffers it passed.  On the root, received(r) is the latest
-    (bytes, nbytes) of peer r >= 1 once its handles have been waited on.
+    reuses the buffers it passed.  On the root, received(r) is what peer r >= 1
+    sent in the most recently STARTED gather, once its handles have been waited
+    on; the root keeps two sets of receive buffers and alternates between them
+    like the caller does with its outputs, so that with two gathers in flight
+    the older one's data is not overwritten by the newer one's arrival
+    (received(r, slot) names a set: the k-th start() fills set k & 1).
 
     cols: how many columns of the [nstreams, frames_cap] byte buffer can hold
     data at all (the caller knows its streams' lengths: mifsk_max_frames of the
@@ -386,9 +390,10 @@ class ByteGatherer:
     def __init__(self, dist, rank, world, cols=None, rows=None):
         self.dist, self.rank, self.world = dist, rank, world
         self.cols, self.rows = cols, rows
-        self._rx = None
+        self._rx = [None, None]
         self._tx = [None, None]
         self._k = 0
+        self._last = 0
 
     def bytes_per_peer(self, nstreams):
         """what one peer sends per step (bytes + counts)"""
@@ -401,16 +406,20 @@ class ByteGatherer:
         cols = local_bytes.shape[1] if self.cols is None else min(int(self.cols), local_bytes.shape[1])
         self.cols = cols
         if self.rank == 0:
-            if self._rx is None:
+            slot = self._k & 1
+            self._k += 1
+            self._last = slot
+            if self._rx[slot] is None:
                 torch = _torch()
                 rows = self.rows or [local_bytes.shape[0]] * self.world
-                self._rx = [(torch.empty((rows[r], cols), dtype=local_bytes.dtype, device=local_bytes.device),
-                             torch.empty((rows[r],), dtype=local_nbytes.dtype, device=local_nbytes.device))
-                            for r in range(1, self.world)]
+                self._rx[slot] = [(torch.empty((rows[r], cols), dtype=local_bytes.dtype, device=local_bytes.device),
+                                   torch.empty((rows[r],), dtype=local_nbytes.dtype, device=local_nbytes.device))
+                                  for r in range(1, self.world)]
+            rx = self._rx[slot]
             ops = []
             for r in range(1, self.world):
-                ops.append(dist.P2POp(dist.irecv, self._rx[r - 1][0], r))
-                ops.append(dist.P2POp(dist.irecv, self._rx[r - 1][1], r))
+                ops.append(dist.P2POp(dist.irecv, rx[r - 1][0], r))
+                ops.append(dist.P2POp(dist.irecv, rx[r - 1][1], r))
         else:
             tx = local_bytes
             if cols != local_bytes.shape[1]:
@@ -424,8 +433,8 @@ class ByteGatherer:
             ops = [dist.P2POp(dist.isend, tx, 0), dist.P2POp(dist.isend, local_nbytes, 0)]
         return dist.batch_isend_irecv(ops)
 
-    def received(self, r):
-        return self._rx[r - 1]
+    def received(self, r, slot=None):
+        return self._rx[self._last if slot is None else slot & 1][r - 1]
 
 
 DECODERS = {"ascii8": 0, "baudot": 1, "binary": 2, "callerid": 3, "uic-ground": 4, "uic-train": 5}

@@ -38,6 +38,7 @@ enum {
     OPT_RING_EXACT, OPT_FLAT, OPT_STATS
 };
 
+#ifndef MIFSK_CLI_NO_MAIN
 static void usage( void )
 {
     fprintf(stderr,
@@ -92,6 +93,84 @@ static int write_wav( const char *path, const float *x, size_t n, unsigned rate,
     return fclose(f);
 }
 
+#endif /* MIFSK_CLI_NO_MAIN */
+
+/* Everything `minimodem --rx --file F [--file G ...]` prints, through the batch entry: the
+ * files as ONE batch on the MI355X, then each file's text (stdout) and CARRIER / NOCARRIER
+ * lines (stderr) in command-line order.  `a` is the command line as data (what was given;
+ * zero / negative = not given, as the options leave minimodem's own variables).  Returns the
+ * process's exit status.  Also what integration/minimodem-rx-batch.patch calls from inside the
+ * reference's own main() (there with one file: the reference takes one --file). */
+enum { MIFSK_CLI_FLAT = 1, MIFSK_CLI_QUIET = 2, MIFSK_CLI_PRINT_FILTER = 4, MIFSK_CLI_STATS = 8 };
+
+int mifsk_cli_rx_files( const mifsk_modem_args *a, const char *const *files, int nfiles, float rxnoise,
+	unsigned flags )
+{
+    /* ---- receive: every --file of the command line as ONE batch --------------------
+     * (headers parsed, raw samples pread() into pinned memory, copied and converted on
+     * the device, demodulated chunk by chunk: mifsk_demod_files) */
+    const int flat = ( flags & MIFSK_CLI_FLAT ) != 0, quiet = ( flags & MIFSK_CLI_QUIET ) != 0;
+    const int print_filter = ( flags & MIFSK_CLI_PRINT_FILTER ) != 0, stats = ( flags & MIFSK_CLI_STATS ) != 0;
+    mifsk_ctx *ctx = NULL;
+    int rc = mifsk_ctx_create(&ctx, -1);
+    if ( rc ) {
+	fprintf(stderr, "E: no MI355X available (%d); this program has no CPU receive path\n", rc);
+	return 1;
+    }
+    mifsk_files *res = NULL;
+    rc = mifsk_demod_files(ctx, a, files, nfiles, rxnoise,
+			   flat ? 0u : MIFSK_IO_RING_EXACT, &res);
+    if ( rc ) {
+	fprintf(stderr, "E: mifsk_demod_files failed (%d)\n", rc);
+	return 1;
+    }
+    const unsigned tflags = ( print_filter ? MIFSK_TEXT_PRINT_FILTER : 0 ) | ( quiet ? MIFSK_TEXT_QUIET : 0 );
+    int failed = 0;
+    for ( int i = 0; i < nfiles; i++ ) {
+	const mifsk_file_result *fr = mifsk_files_get(res, i);
+	if ( nfiles > 1 && !quiet )
+	    fprintf(stderr, "### FILE %s\n", files[i]);
+	if ( fr->error ) {
+	    if ( fr->error == -EINVAL || fr->error == -ENOTSUP )
+		fprintf(stderr, "E: %s: not a mono PCM16 / float32 WAV file (%d)\n", files[i], fr->error);
+	    else
+		fprintf(stderr, "E: %s: %s\n", files[i], strerror(-fr->error));
+	    failed = 1;
+	    continue;
+	}
+	if ( fr->status & ( MIFSK_STREAM_ABORTED | MIFSK_STREAM_FRAMES_TRUNCATED | MIFSK_STREAM_EPISODES_TRUNCATED ) ) {
+	    fprintf(stderr, "E: %s: receive loop %s (status %u)\n", files[i],
+		    fr->status & MIFSK_STREAM_ABORTED ? "aborted" : "ran out of output room", fr->status);
+	    failed = 1;
+	}
+	size_t out_len = 0, err_len = 0;
+	const size_t out_cap = 64 + 320 * (size_t)( fr->nframes ? fr->nframes : 1 );
+	const size_t err_cap = 256 + 512 * (size_t)( fr->nepisodes ? fr->nepisodes : 1 );
+	char *out = malloc(out_cap), *err = malloc(err_cap);
+	rc = mifsk_stream_text(fr->cfg, fr->bits, fr->nframes, fr->episodes, fr->nepisodes, tflags,
+			       out, out_cap, &out_len, err, err_cap, &err_len);
+	if ( rc && rc != -ENOSPC ) {
+	    failed = 1;
+	} else {
+	    fwrite(err, 1, err_len < err_cap ? err_len : err_cap, stderr);
+	    fwrite(out, 1, out_len < out_cap ? out_len : out_cap, stdout);
+	    fflush(stdout);
+	}
+	free(out);
+	free(err);
+    }
+    if ( stats && !quiet ) {
+	const mifsk_host_stats *st = mifsk_files_stats(res);
+	fprintf(stderr, "### BATCH files=%u chunks=%u h2d=%.1f MB in %.3f s (%.2f GB/s, staging %.3f s)\n",
+		st->streams, st->chunks, st->bytes_h2d / 1e6, st->seconds_total,
+		st->seconds_total > 0 ? st->bytes_h2d / st->seconds_total / 1e9 : 0.0, st->seconds_staging);
+    }
+    mifsk_files_free(res);
+    mifsk_ctx_destroy(ctx);
+    return failed;
+}
+
+#ifndef MIFSK_CLI_NO_MAIN
 int main( int argc, char *argv[] )
 {
     int tx_mode = -1;
@@ -207,64 +286,8 @@ int main( int argc, char *argv[] )
 	return rc ? 1 : 0;
     }
 
-    /* ---- receive: every --file of the command line as ONE batch --------------------
-     * (headers parsed, raw samples pread() into pinned memory, copied and converted on
-     * the device, demodulated chunk by chunk: mifsk_demod_files) */
-    mifsk_ctx *ctx = NULL;
-    rc = mifsk_ctx_create(&ctx, -1);
-    if ( rc ) {
-	fprintf(stderr, "E: no MI355X available (%d); this program has no CPU receive path\n", rc);
-	return 1;
-    }
-    mifsk_files *res = NULL;
-    rc = mifsk_demod_files(ctx, &a, (const char *const *)files, nfiles, rxnoise,
-			   flat ? 0u : MIFSK_IO_RING_EXACT, &res);
-    if ( rc ) {
-	fprintf(stderr, "E: mifsk_demod_files failed (%d)\n", rc);
-	return 1;
-    }
-    const unsigned tflags = ( print_filter ? MIFSK_TEXT_PRINT_FILTER : 0 ) | ( quiet ? MIFSK_TEXT_QUIET : 0 );
-    int failed = 0;
-    for ( int i = 0; i < nfiles; i++ ) {
-	const mifsk_file_result *fr = mifsk_files_get(res, i);
-	if ( nfiles > 1 && !quiet )
-	    fprintf(stderr, "### FILE %s\n", files[i]);
-	if ( fr->error ) {
-	    if ( fr->error == -EINVAL || fr->error == -ENOTSUP )
-		fprintf(stderr, "E: %s: not a mono PCM16 / float32 WAV file (%d)\n", files[i], fr->error);
-	    else
-		fprintf(stderr, "E: %s: %s\n", files[i], strerror(-fr->error));
-	    failed = 1;
-	    continue;
-	}
-	if ( fr->status & ( MIFSK_STREAM_ABORTED | MIFSK_STREAM_FRAMES_TRUNCATED | MIFSK_STREAM_EPISODES_TRUNCATED ) ) {
-	    fprintf(stderr, "E: %s: receive loop %s (status %u)\n", files[i],
-		    fr->status & MIFSK_STREAM_ABORTED ? "aborted" : "ran out of output room", fr->status);
-	    failed = 1;
-	}
-	size_t out_len = 0, err_len = 0;
-	const size_t out_cap = 64 + 320 * (size_t)( fr->nframes ? fr->nframes : 1 );
-	const size_t err_cap = 256 + 512 * (size_t)( fr->nepisodes ? fr->nepisodes : 1 );
-	char *out = malloc(out_cap), *err = malloc(err_cap);
-	rc = mifsk_stream_text(fr->cfg, fr->bits, fr->nframes, fr->episodes, fr->nepisodes, tflags,
-			       out, out_cap, &out_len, err, err_cap, &err_len);
-	if ( rc && rc != -ENOSPC ) {
-	    failed = 1;
-	} else {
-	    fwrite(err, 1, err_len < err_cap ? err_len : err_cap, stderr);
-	    fwrite(out, 1, out_len < out_cap ? out_len : out_cap, stdout);
-	    fflush(stdout);
-	}
-	free(out);
-	free(err);
-    }
-    if ( stats && !quiet ) {
-	const mifsk_host_stats *st = mifsk_files_stats(res);
-	fprintf(stderr, "### BATCH files=%u chunks=%u h2d=%.1f MB in %.3f s (%.2f GB/s, staging %.3f s)\n",
-		st->streams, st->chunks, st->bytes_h2d / 1e6, st->seconds_total,
-		st->seconds_total > 0 ? st->bytes_h2d / st->seconds_total / 1e9 : 0.0, st->seconds_staging);
-    }
-    mifsk_files_free(res);
-    mifsk_ctx_destroy(ctx);
-    return failed;
+    return mifsk_cli_rx_files(&a, (const char *const *)files, nfiles, rxnoise,
+			      ( flat ? MIFSK_CLI_FLAT : 0 ) | ( quiet ? MIFSK_CLI_QUIET : 0 )
+			      | ( print_filter ? MIFSK_CLI_PRINT_FILTER : 0 ) | ( stats ? MIFSK_CLI_STATS : 0 ));
 }
+#endif /* MIFSK_CLI_NO_MAIN */

@@ -877,6 +877,11 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
     const bool h_msb = cfg.msb_first != 0u;
     const bool h_rx_sync = cfg.do_rx_sync != 0u;
     const uint64_t h_sync_byte = keep_scalar(cfg.sync_byte);
+    // ... and what an iteration of the general path reads (one per refinement: hundreds per
+    // stream on a noisy signal)
+    const uint32_t h_try_max0 = keep_scalar(cfg.try_max[0]), h_try_max1 = keep_scalar(cfg.try_max[1]);
+    const uint32_t h_try_step0 = keep_scalar(cfg.try_step[0]), h_try_step1 = keep_scalar(cfg.try_step[1]);
+    const uint32_t h_first0 = keep_scalar(cfg.try_first[0]);
     // LINEAR rounds are cheap (coalesced staging, short windows): never speculate
     // less than one round; DIRECT rounds stream whole windows per lane
     if ( lat_mode == LAT_LINEAR )
@@ -1167,19 +1172,19 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 		advance = 0;
 	    }
 	    const uint32_t avail = N - base;
-	    if ( avail == 0 || avail < cfg.expect_nsamples )
+	    if ( avail == 0 || avail < h_expect )
 		break;
 	}
 	ctx.bump(MIFSK_CNT_ITERATIONS);
 	const uint32_t t_gen = MIFSK_CLOCK();
 
 	const uint32_t ci = carrier ? 1u : 0u;
-	const uint32_t try_max = cfg.try_max[ci];
-	const uint32_t try_step = cfg.try_step[ci];
-	const uint32_t try_first = cfg.try_first[ci];
+	const uint32_t try_max = carrier ? h_try_max1 : h_try_max0;
+	const uint32_t try_step = carrier ? h_try_step1 : h_try_step0;
+	const uint32_t try_first = carrier ? h_first1 : h_first0;
 
 	const uint32_t t_s1 = MIFSK_CLOCK();
-	ScanResult sr =ctx.scan(base, carrier ? zc1 : zc0, try_first, cfg.search_limit,
+	ScanResult sr =ctx.scan(base, carrier ? zc1 : zc0, try_first, h_limit,
 				 carrier ? 0u : 1u);		// minimodem.c:1265-1274
 	cyc_s1 += MIFSK_CLOCK() - t_s1;
 	float confidence = sr.conf;
@@ -1195,7 +1200,7 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 	if ( amplitude < track_amplitude * 0.25f )		// minimodem.c:1286-1288
 	    confidence = 0.0f;
 
-	if ( confidence <= cfg.conf_threshold ) {		// minimodem.c:1292-1321
+	if ( confidence <= h_thr ) {				// minimodem.c:1292-1321
 	    if ( ++noconfidence > 20u ) {
 		    if ( carrier ) {
 
@@ -1225,11 +1230,11 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 	    continue;
 	}
 
-	carrier_nsamples += cfg.frame_nsamples;			// minimodem.c:1324
+	carrier_nsamples += h_fn;				// minimodem.c:1324
 	uint32_t flags = 0;
 	if ( carrier ) {
 	    carrier_nsamples += frame_start;			// minimodem.c:1329-1330
-	    carrier_nsamples -= cfg.overscan;
+	    carrier_nsamples -= h_overscan;
 	} else {
 	    carrier = true;					// minimodem.c:1350-1353
 	    refine = true;
@@ -1268,10 +1273,12 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 	nframes_decoded++;
 	noconfidence = 0;
 
-	advance = frame_start + cfg.frame_nsamples - cfg.overscan;	// minimodem.c:1407
+	advance = frame_start + h_fn - h_overscan;			// minimodem.c:1407
 
-	bits = data_bits_of(cfg, bits);					// minimodem.c:1415-1428
-	const bool suppressed = cfg.do_rx_sync && bits == cfg.sync_byte;	// minimodem.c:1436-1439
+	bits = ( bits >> h_dshift ) & h_dmask;				// data_bits_of(), minimodem.c:1415-1428
+	if ( h_msb )
+	    bits = bit_reverse(bits, cfg.n_data_bits);
+	const bool suppressed = h_rx_sync && bits == h_sync_byte;	// minimodem.c:1436-1439
 	if ( suppressed )
 	    flags |= MIFSK_FRAME_SYNC;
 

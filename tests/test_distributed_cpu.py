@@ -253,13 +253,16 @@ def _world8_worker(rank, world, port, q):
             # what the root holds of every peer after step `step`'s gather has been waited on
             n = 0
             for r in range(1, world):
-                rb, rn = g.received(r)
+                rb, rn = g.received(r, step)
                 plo, phi = spans[r]
                 assert tuple(rb.shape) == (phi - plo, cols) and tuple(rn.shape) == (phi - plo,)
                 gid = torch.arange(plo, phi, dtype=torch.int64).reshape(-1, 1)
                 j = torch.arange(cols, dtype=torch.int64).reshape(1, -1)
-                assert torch.equal(rb, ((gid + 3 * j + step) % 251).to(torch.uint8)), (r, step)
-                assert torch.equal(rn, ((torch.arange(plo, phi) + step) % (cols + 1)).to(torch.int32)), (r, step)
+                # (rank 5's launch of step 3 failed: it still joined the gather, with what its
+                # buffer held -- step 1's bytes)
+                es = step - 2 if (r == 5 and step == 3) else step
+                assert torch.equal(rb, ((gid + 3 * j + es) % 251).to(torch.uint8)), (r, step)
+                assert torch.equal(rn, ((torch.arange(plo, phi) + es) % (cols + 1)).to(torch.int32)), (r, step)
                 n += phi - plo
             return n
 

@@ -51,3 +51,28 @@ def test_reference_main_over_libmifsk(name, tmp_path):
     assert r.stdout == g["stdout"]
     lines = [l for l in r.stderr.decode().splitlines() if l.startswith("### NOCARRIER")]
     assert lines == g["nocarrier"]
+
+
+RXBATCH = os.path.join(O.REF_DIR, "minimodem_mifsk_rxbatch")
+
+
+@pytest.mark.skipif(not os.path.exists(RXBATCH), reason="oracle/_ref/minimodem_mifsk_rxbatch not built")
+@pytest.mark.parametrize("name", G.names())
+def test_reference_main_with_the_rx_batch_patch(name, tmp_path):
+    """The reference's own main() with integration/minimodem-rx-batch.patch applied (oracle/Makefile
+    applies it to a scratch copy at build time): `--rx --file` leaves main() before its receive
+    loop and goes through libmifsk's batch entry -- whole file to the device, the loop on the
+    device, frame bits through the databits post-pass.  Same command lines, same expectations
+    as the unpatched drop-in above: the reference's stdout byte for byte, its NOCARRIER
+    statistics line character for character, on every golden."""
+    g = G.load(name)
+    z = np.load(os.path.join(G.GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+    rx_args = [str(a) for a in z["rx_args"].tolist()]
+    wav = str(tmp_path / "in.wav")
+    _write_wav(wav, g)
+    r = subprocess.run([RXBATCH, "--rx", "--file", wav] + rx_args,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout == g["stdout"]
+    lines = [l for l in r.stderr.decode().splitlines() if l.startswith("### NOCARRIER")]
+    assert lines == g["nocarrier"]
