@@ -36,7 +36,7 @@ extern "C" {
 #endif
 
 #define MIFSK_MAX_FRAME_BITS	64	/* fsk.c:185-187,463 */
-#define MIFSK_ABI_VERSION	6
+#define MIFSK_ABI_VERSION	7
 
 /* which databits decoder main() would have selected (minimodem.c:549-553,
  * 675,820,856,866,892).  Decoding frame bits to text is O(1)/frame host work
@@ -265,7 +265,7 @@ typedef struct mifsk_demod_io {
 #define MIFSK_IO_ENGINE_WAVE	4u
 
 /* per-stream work counters (diagnostics; cycle counts are s_memtime ticks) */
-#define MIFSK_NCOUNTERS		24
+#define MIFSK_NCOUNTERS		32
 #define MIFSK_CNT_ITERATIONS	0	/* passes through the general loop body  */
 #define MIFSK_CNT_BATCHES	1	/* candidate batches evaluated           */
 #define MIFSK_CNT_STAGES	2	/* LDS slab (re)loads                    */
@@ -279,6 +279,11 @@ typedef struct mifsk_demod_io {
 #define MIFSK_CNT_CYC_WAIT	10	/* LATTICE: master waiting for workers   */
 #define MIFSK_CNT_CYC_CONFIDENCE 11
 #define MIFSK_CNT_CYC_BULK	12
+/* (13 .. 23: cycle totals of the profile build; 20 .. 22 double as event counts of the
+ * shared-segment scans and of --auto-carrier) */
+#define MIFSK_CNT_CONF_FALLBACKS 24	/* confidence passes that took the divisions proper (a
+					   zero / non-finite class mean or a subnormal quotient
+					   somewhere in the wave: frame_confidence_fixed)          */
 
 /* Asynchronous on `stream`: the outputs are complete when `stream` reaches the point
  * behind the call.  (A large wavefront-engine batch is run as several launches on

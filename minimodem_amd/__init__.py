@@ -34,11 +34,12 @@ SEARCH_DTYPE = np.dtype([("sample_offset", "<u8"), ("navail", "<u4"), ("try_firs
 RESULT_DTYPE = np.dtype([("bits", "<u8"), ("confidence", "<f4"), ("amplitude", "<f4"),
                          ("frame_start", "<u4"), ("n_positions", "<u4")])
 assert SEARCH_DTYPE.itemsize == 32 and RESULT_DTYPE.itemsize == 24
-NCOUNTERS = 24
+NCOUNTERS = 32
 COUNTER_NAMES = {0: "iterations", 1: "batches", 2: "stages", 3: "bulk_frames", 4: "refines",
                  5: "cache_hits", 6: "positions", 7: "lattice_batches", 8: "cyc_total",
                  9: "cyc_scan", 10: "cyc_wait", 11: "cyc_confidence", 12: "cyc_bulk", 13: "w_stage", 14: "w_correlate",
-                 15: "w_barrier", 16: "cyc_general", 17: "cyc_restart", 18: "cyc_scan1", 19: "cyc_scan2", 20: "cyc_replay_scan", 21: "cyc_scan_wait"}
+                 15: "w_barrier", 16: "cyc_general", 17: "cyc_restart", 18: "cyc_scan1", 19: "cyc_scan2", 20: "cyc_replay_scan", 21: "cyc_scan_wait",
+                 24: "conf_fallbacks"}
 
 
 def build(force=False):

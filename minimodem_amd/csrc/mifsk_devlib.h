@@ -176,7 +176,7 @@ __device__ __forceinline__ bool float_is_subnormal( float t )
 // wave through the divisions proper).
 template <int NB>
 __device__ __forceinline__ FrameOut
-frame_confidence_fixed( const float2 *mags, uint64_t req_mask, uint64_t req_val )
+frame_confidence_fixed( const float2 *mags, uint64_t req_mask, uint64_t req_val, uint32_t *fell_back = nullptr )
 {
     FrameOut out;
     out.conf = 0.0f;
@@ -241,6 +241,8 @@ frame_confidence_fixed( const float2 *mags, uint64_t req_mask, uint64_t req_val 
     if ( __any(odd) ) {
 	// a divisor that is zero, infinite or NaN, or a subnormal quotient, somewhere in the
 	// wave: the divisions proper, for everybody (uniform branch, practically never taken)
+	if ( fell_back )
+	    *fell_back = 1u;		// (MIFSK_CNT_CONF_FALLBACKS: tests/test_gpu_parity.py drives this arm)
 	avg_sig = total_sig / (float)NB;
 #pragma unroll
 	for ( int k = 0; k < NB; k++ ) {
@@ -283,7 +285,7 @@ frame_confidence_fixed( const float2 *mags, uint64_t req_mask, uint64_t req_val 
 // Bit for bit the results of frame_confidence_fixed (every parity test runs through it).
 template <int NB>
 __device__ __forceinline__ FrameOut
-frame_confidence_staged( const float2 *mags, uint64_t req_mask, uint64_t req_val )
+frame_confidence_staged( const float2 *mags, uint64_t req_mask, uint64_t req_val, uint32_t *fell_back = nullptr )
 {
     FrameOut out;
     out.conf = 0.0f;
@@ -364,6 +366,8 @@ frame_confidence_staged( const float2 *mags, uint64_t req_mask, uint64_t req_val
     odd = odd || float_is_subnormal(div_n);
     if ( __any(odd) ) {
 	// (as in frame_confidence_fixed: the divisions proper, for everybody, practically never)
+	if ( fell_back )
+	    *fell_back = 1u;
 	avg_sig = total_sig / (float)NB;
 #pragma unroll
 	for ( int k = 0; k < NB; k++ ) {
@@ -388,32 +392,30 @@ frame_confidence_staged( const float2 *mags, uint64_t req_mask, uint64_t req_val
 // frame lengths with a specialised confidence pass: start + 8 data + stop with
 // the previous stop bit (11), the 7-bit variant (10); everything else is generic
 __device__ __forceinline__ FrameOut
-frame_confidence_any( const float2 *mags, uint64_t req_mask, uint64_t req_val, uint32_t n_bits )
+frame_confidence_any( const float2 *mags, uint64_t req_mask, uint64_t req_val, uint32_t n_bits,
+	uint32_t *fell_back = nullptr )
 {
     if ( n_bits == 11u )
-	return frame_confidence_fixed<11>(mags, req_mask, req_val);
+	return frame_confidence_fixed<11>(mags, req_mask, req_val, fell_back);
     if ( n_bits == 10u )
-	return frame_confidence_fixed<10>(mags, req_mask, req_val);
+	return frame_confidence_fixed<10>(mags, req_mask, req_val, fell_back);
     if ( n_bits == 8u )					// RTTY "10ddddd1", SAME "dddddddd"
-	return frame_confidence_fixed<8>(mags, req_mask, req_val);
+	return frame_confidence_fixed<8>(mags, req_mask, req_val, fell_back);
     return frame_confidence(mags, req_mask, req_val, n_bits);
 }
 
 // ... for the lone, latency-bound wave (the workgroup engine's master)
 __device__ __forceinline__ FrameOut
-frame_confidence_any_staged( const float2 *mags, uint64_t req_mask, uint64_t req_val, uint32_t n_bits )
+frame_confidence_any_staged( const float2 *mags, uint64_t req_mask, uint64_t req_val, uint32_t n_bits,
+	uint32_t *fell_back = nullptr )
 {
-#ifndef MIFSK_X_NOSTAGED
     if ( n_bits == 11u )
-	return frame_confidence_staged<11>(mags, req_mask, req_val);
+	return frame_confidence_staged<11>(mags, req_mask, req_val, fell_back);
     if ( n_bits == 10u )
-	return frame_confidence_staged<10>(mags, req_mask, req_val);
+	return frame_confidence_staged<10>(mags, req_mask, req_val, fell_back);
     if ( n_bits == 8u )
-	return frame_confidence_staged<8>(mags, req_mask, req_val);
+	return frame_confidence_staged<8>(mags, req_mask, req_val, fell_back);
     return frame_confidence(mags, req_mask, req_val, n_bits);
-#else
-    return frame_confidence_any(mags, req_mask, req_val, n_bits);
-#endif
 }
 
 // what one fsk_find_frame() returns (fsk.c:504-511)

@@ -468,7 +468,11 @@ struct Master {
 	cyc_wait += t_c - t_w;
 	bump(MIFSK_CNT_LATTICE_BATCHES);
 	if ( lane < frames ) {
-	    const FrameOut fo = frame_confidence_any_staged(&lds->mags[buf][conf_idx], h_req_mask, h_req_val, h_nbits);
+	    uint32_t fb = 0u;
+	    const FrameOut fo = frame_confidence_any_staged(&lds->mags[buf][conf_idx], h_req_mask, h_req_val, h_nbits,
+							    cnt_on ? &fb : nullptr);
+	    if ( cnt_on && fb )
+		bump(MIFSK_CNT_CONF_FALLBACKS);
 	    lds->c_conf[lane] = fo.conf;
 	    lds->c_ampl[lane] = fo.ampl;
 	    lds->c_bits[lane] = fo.bits;
@@ -525,8 +529,11 @@ struct Master {
 	const uint32_t t_conf = MIFSK_CLOCK();
 	cyc_par += t_conf - t_par;
 	if ( lane < nq ) {
+	    uint32_t fb = 0u;
 	    const FrameOut f = frame_confidence_any_staged(&lds->mags[0][lane * cfg.n_bits],
-						cfg.req_mask[kind], cfg.req_val[kind], cfg.n_bits);
+						cfg.req_mask[kind], cfg.req_val[kind], cfg.n_bits, cnt_on ? &fb : nullptr);
+	    if ( cnt_on && fb )
+		bump(MIFSK_CNT_CONF_FALLBACKS);
 	    lds->c_conf[lane] = f.conf;
 	    lds->c_ampl[lane] = f.ampl;
 	    lds->c_bits[lane] = f.bits;
@@ -680,8 +687,12 @@ struct Master {
 	const uint32_t t_sf2 = MIFSK_CLOCK();
 	FrameOut f;
 	f.conf = 0.0f; f.ampl = 0.0f; f.bits = 0;
-	if ( lane < zz.J - 1u )
-	    f = frame_confidence_any_staged(&sm[lane * nb], cfg.req_mask[0], cfg.req_val[0], nb);
+	if ( lane < zz.J - 1u ) {
+	    uint32_t fb = 0u;
+	    f = frame_confidence_any_staged(&sm[lane * nb], cfg.req_mask[0], cfg.req_val[0], nb, cnt_on ? &fb : nullptr);
+	    if ( cnt_on && fb )
+		bump(MIFSK_CNT_CONF_FALLBACKS);
+	}
 	bump(MIFSK_CNT_POSITIONS, zz.J - 1u);
 	const uint32_t t_sf3 = MIFSK_CLOCK();
 	// fsk.c:492-501 in scan order, candidate 0 first; the limit of this scan

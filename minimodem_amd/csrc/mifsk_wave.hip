@@ -431,7 +431,10 @@ struct Wave {
 	fo.conf = 0.0f; fo.ampl = 0.0f; fo.bits = 0;
 	if ( lane < F ) {
 	    const uint32_t ci = cfg.lat_grid ? lane * ( nb - 1u ) : lane * nb;
-	    fo = frame_confidence_any(&mags[ci], cfg.req_mask[0], cfg.req_val[0], nb);
+	    uint32_t fb = 0u;
+	    fo = frame_confidence_any(&mags[ci], cfg.req_mask[0], cfg.req_val[0], nb, cnt_on ? &fb : nullptr);
+	    if ( cnt_on && fb )
+		bump(MIFSK_CNT_CONF_FALLBACKS);
 	}
 	un_valid = false;			// (a block's windows may have gone through the tile)
 	l_conf = fo.conf;
@@ -940,8 +943,12 @@ struct Wave {
 	    const uint32_t ts2 = MIFSK_WCLOCK();
 	    FrameOut f;
 	    f.conf = 0.0f; f.ampl = 0.0f; f.bits = 0;
-	    if ( lane < Q )
-		f = frame_confidence_any(&mags[lane * nb], cfg.req_mask[kind], cfg.req_val[kind], nb);
+	    if ( lane < Q ) {
+		uint32_t fb = 0u;
+		f = frame_confidence_any(&mags[lane * nb], cfg.req_mask[kind], cfg.req_val[kind], nb, cnt_on ? &fb : nullptr);
+		if ( cnt_on && fb )
+		    bump(MIFSK_CNT_CONF_FALLBACKS);
+	    }
 	    wave_lds_sync();			// mags[] is free again
 	    cyc_s_stage += ts1 - ts0;
 	    cyc_s_corr += ts2 - ts1;

@@ -98,7 +98,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS), (declared ^ set(_lib.EXPORTS))
     for name in sorted(declared):
         assert hasattr(lib, name), name
-    assert lib.mifsk_abi_version() == 6
+    assert lib.mifsk_abi_version() == 7
 
 
 def test_scan_plans_cover_their_windows():

@@ -616,3 +616,60 @@ def test_non_finite_samples_give_the_oracles_frames(gpu, mode, variant):
         assert int(res["status"][i]) == 0
         total += nf
     assert total > (40 if mode == "rtty" else 100)
+
+
+@pytest.mark.parametrize("variant", VARIANTS, ids=VARIANT_IDS)
+@pytest.mark.parametrize("mode", ["1200", "12000", "same", "rtty"])
+def test_subnormal_scale_audio_takes_the_division_fallback_and_matches_the_oracle(gpu, mode, variant):
+    """Audio at amplitudes of 1e-38 ... 1e-44 (float subnormals): magnitudes, class means and
+    `avg_sig` are subnormal, the noise bin is below FLT_EPSILON (so confidences are infinite or
+    NaN, fsk.c:279,292) -- and the fast quotients of the confidence pass (div_by_rcp: exact
+    only for normal quotients) must hand over to the divisions proper.  The frames must be
+    the oracle's bit for bit, and the work counter MIFSK_CNT_CONF_FALLBACKS must show that
+    the fallback arm of frame_confidence_fixed is what ran."""
+    M, torch, ctx = gpu
+    engine, ring = variant
+    cfg = M.rx_config(mode)
+    ocfg = O.oracle_config(mode)
+    rng = np.random.default_rng(1938)
+    five = cfg.n_data_bits == 5
+    amps = [1e-38, 3e-39, 1e-40, 1e-42, 1e-44, 1.0, 9e-39]
+    streams = []
+    for i, a in enumerate(amps):
+        nw = {"rtty": 8, "12000": 300}.get(mode, 60)
+        words = rng.integers(0 if five else 32, 32 if five else 127, size=nw + i, dtype=np.uint8)
+        # (generated at amplitude 1 and scaled in double: what a recorder with that gain would store)
+        x = M.synthesize(cfg, words, leading_silence=int(rng.integers(0, 50)), amplitude=1.0)
+        x = (x.astype(np.float64) * a).astype(np.float32)
+        if i == 6:
+            # a normal-scale stretch in the middle: the loop crosses between the two arms
+            x[len(x) // 3: 2 * len(x) // 3] = (x[len(x) // 3: 2 * len(x) // 3].astype(np.float64) * 1e38).astype(np.float32)
+        streams.append(x)
+    assert any(np.any((np.abs(s) > 0) & (np.abs(s) < np.finfo(np.float32).tiny)) for s in streams)
+    res = run_gpu_streams(M, torch, ctx, cfg, streams, want=("bytes", "frames", "episodes", "bits", "counters"),
+                          engine=engine, ring=ring)
+    total = 0
+    for i, s in enumerate(streams):
+        ref = O.oracle_rx_stream(ocfg, s, ring_mode=ring)
+        nf = int(res["nframes"][i])
+        assert nf == len(ref["frames"]), (mode, i, nf, len(ref["frames"]))
+        got, exp = res["frames"][i, :nf], ref["frames"]
+        for field in ("bits", "start", "flags"):
+            assert np.array_equal(got[field], exp[field]), (mode, i, field)
+        for field in ("confidence", "amplitude"):
+            assert _same_or_both_nan(got[field], exp[field]), (mode, i, field)
+        assert res["bytes"][i, :int(res["nbytes"][i])].tobytes() == ref["bytes"]
+        ne = int(res["nepisodes"][i])
+        assert ne == len(ref["episodes"])
+        for field in ("carrier_nsamples", "first_frame", "nframes", "end_reason", "b_mark"):
+            assert np.array_equal(res["episodes"][i, :ne][field], ref["episodes"][field]), (mode, i, field)
+        for field in ("confidence_total", "amplitude_total"):
+            assert _same_or_both_nan(res["episodes"][i, :ne][field], ref["episodes"][field]), (mode, i, field)
+        total += nf
+    fb = res["counters"][:, 24]
+    # every stream whose samples are subnormal and that produced a frame at all went through the
+    # fallback (the amplitude-1 stream may have, too: a candidate lying in digital silence has
+    # a class mean of exactly 0)
+    took = [i for i in range(len(amps)) if i != 5 and int(res["nframes"][i]) > 0]
+    assert took and all(int(fb[i]) > 0 for i in took), (fb, res["nframes"])
+    assert total > 0
