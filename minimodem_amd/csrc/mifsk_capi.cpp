@@ -616,6 +616,11 @@ static void derive_cfg( mifsk_ctx *ctx, const mifsk_rx_config &cfg, DevCfg &d )
     }
     mifsk::fill_devcfg(d, cfg);
     std::lock_guard<std::mutex> g(ctx->lock);
+    // (another caller with the same configuration may have filled it in while this one derived:
+    // keep one entry per key)
+    for ( const mifsk_ctx::DerivedCfg &e : ctx->derived )
+	if ( std::memcmp(&e.key, &cfg, sizeof(cfg)) == 0 )
+	    return;
     constexpr size_t kKeep = 8;
     if ( ctx->derived.size() < kKeep ) {
 	ctx->derived.push_back(mifsk_ctx::DerivedCfg{cfg, d});
@@ -926,6 +931,8 @@ extern "C" int mifsk_demod_slab( mifsk_ctx *ctx, const mifsk_rx_config *cfg, con
 {
     if ( !ctx || !io || !d_state || mifsk_check_cfg(cfg) )
 	return -EINVAL;
+    if ( cfg->samplebuf_size < 2u )		// (the loop refills half a buffer at a time)
+	return -EINVAL;
     if ( io->nstreams < 0 || ( io->nstreams > 0 && !io->d_samples ) )
 	return -EINVAL;
     if ( io->stream_stride % 4 != 0 || ( (uintptr_t)io->d_samples & 15u ) )
@@ -980,7 +987,7 @@ extern "C" size_t mifsk_ring_floats( const mifsk_rx_config *cfg )
 extern "C" int mifsk_demod_slab_ring( mifsk_ctx *ctx, const mifsk_rx_config *cfg, const mifsk_demod_io *io,
 	mifsk_stream_state *d_state, const uint64_t *d_origin, float *d_ring, int final, void *stream )
 {
-    if ( !ctx || !io || !d_state || !d_ring || mifsk_check_cfg(cfg) )
+    if ( !ctx || !io || !d_state || !d_ring || mifsk_check_cfg(cfg) || cfg->samplebuf_size < 2u )
 	return -EINVAL;
     if ( io->nstreams < 0 || ( io->nstreams > 0 && !io->d_samples ) )
 	return -EINVAL;

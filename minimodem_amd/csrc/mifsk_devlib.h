@@ -176,7 +176,7 @@ __device__ __forceinline__ bool float_is_subnormal( float t )
 // wave through the divisions proper).
 template <int NB>
 __device__ __forceinline__ FrameOut
-frame_confidence_fixed( const float2 *mags, uint64_t req_mask, uint64_t req_val, uint32_t *fell_back = nullptr )
+frame_confidence_fixed( const float2 *mags, uint64_t req_mask, uint64_t req_val, uint32_t &fell_back )
 {
     FrameOut out;
     out.conf = 0.0f;
@@ -241,8 +241,7 @@ frame_confidence_fixed( const float2 *mags, uint64_t req_mask, uint64_t req_val,
     if ( __any(odd) ) {
 	// a divisor that is zero, infinite or NaN, or a subnormal quotient, somewhere in the
 	// wave: the divisions proper, for everybody (uniform branch, practically never taken)
-	if ( fell_back )
-	    *fell_back = 1u;		// (MIFSK_CNT_CONF_FALLBACKS: tests/test_gpu_parity.py drives this arm)
+	fell_back = 1u;			// (MIFSK_CNT_CONF_FALLBACKS: tests/test_gpu_parity.py drives this arm)
 	avg_sig = total_sig / (float)NB;
 #pragma unroll
 	for ( int k = 0; k < NB; k++ ) {
@@ -285,7 +284,7 @@ frame_confidence_fixed( const float2 *mags, uint64_t req_mask, uint64_t req_val,
 // Bit for bit the results of frame_confidence_fixed (every parity test runs through it).
 template <int NB>
 __device__ __forceinline__ FrameOut
-frame_confidence_staged( const float2 *mags, uint64_t req_mask, uint64_t req_val, uint32_t *fell_back = nullptr )
+frame_confidence_staged( const float2 *mags, uint64_t req_mask, uint64_t req_val, uint32_t &fell_back )
 {
     FrameOut out;
     out.conf = 0.0f;
@@ -366,8 +365,7 @@ frame_confidence_staged( const float2 *mags, uint64_t req_mask, uint64_t req_val
     odd = odd || float_is_subnormal(div_n);
     if ( __any(odd) ) {
 	// (as in frame_confidence_fixed: the divisions proper, for everybody, practically never)
-	if ( fell_back )
-	    *fell_back = 1u;
+	fell_back = 1u;
 	avg_sig = total_sig / (float)NB;
 #pragma unroll
 	for ( int k = 0; k < NB; k++ ) {
@@ -393,7 +391,7 @@ frame_confidence_staged( const float2 *mags, uint64_t req_mask, uint64_t req_val
 // the previous stop bit (11), the 7-bit variant (10); everything else is generic
 __device__ __forceinline__ FrameOut
 frame_confidence_any( const float2 *mags, uint64_t req_mask, uint64_t req_val, uint32_t n_bits,
-	uint32_t *fell_back = nullptr )
+	uint32_t &fell_back )
 {
     if ( n_bits == 11u )
 	return frame_confidence_fixed<11>(mags, req_mask, req_val, fell_back);
@@ -407,7 +405,7 @@ frame_confidence_any( const float2 *mags, uint64_t req_mask, uint64_t req_val, u
 // ... for the lone, latency-bound wave (the workgroup engine's master)
 __device__ __forceinline__ FrameOut
 frame_confidence_any_staged( const float2 *mags, uint64_t req_mask, uint64_t req_val, uint32_t n_bits,
-	uint32_t *fell_back = nullptr )
+	uint32_t &fell_back )
 {
     if ( n_bits == 11u )
 	return frame_confidence_staged<11>(mags, req_mask, req_val, fell_back);

@@ -28,7 +28,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -157,20 +159,40 @@ void parallel_for( size_t n, unsigned nthreads, F fn )
 	for ( size_t i = 0; i < n; i++ ) fn(i);
 	return;
     }
+    // An exception on a worker thread would terminate the process, and one thrown while the
+    // threads are being created would destroy joinable threads (the same): every item runs
+    // inside a try, the first exception is kept, every thread that did start is joined, and
+    // the exception is rethrown on the caller -- whose own catch turns it into an error code
+    // at the C ABI.
     std::atomic<size_t> next(0);
+    std::exception_ptr first;
+    std::mutex first_lock;
     auto body = [&]() {
 	for (;;) {
 	    const size_t i = next.fetch_add(1);
 	    if ( i >= n ) break;
-	    fn(i);
+	    try {
+		fn(i);
+	    } catch ( ... ) {
+		std::lock_guard<std::mutex> g(first_lock);
+		if ( !first )
+		    first = std::current_exception();
+		next.store(n);			// nothing more is started
+	    }
 	}
     };
     std::vector<std::thread> ts;
-    for ( unsigned t = 1; t < nthreads; t++ )
-	ts.emplace_back(body);
+    try {
+	ts.reserve(nthreads);
+	for ( unsigned t = 1; t < nthreads; t++ )
+	    ts.emplace_back(body);
+    } catch ( ... ) {				// thread creation failed: go on with those there are
+    }
     body();
     for ( std::thread &t : ts )
 	t.join();
+    if ( first )
+	std::rethrow_exception(first);
 }
 
 unsigned staging_threads()
@@ -328,7 +350,9 @@ int run_job( mifsk_ctx *ctx, Job &job )
     }
 
     const unsigned nthreads = staging_threads();
-    const char *fault_tag = std::getenv("MIFSK_TEST_FAULT_READ");
+    // (a test hook like every other knob: honoured only with MIFSK_EXPERIMENT set, so that a stray
+    // variable cannot turn production reads into rows of zeros)
+    const char *fault_tag = experiment_env("MIFSK_TEST_FAULT_READ");
     if ( fault_tag && !*fault_tag )
 	fault_tag = nullptr;
     double t_stage = 0.0;

@@ -470,7 +470,7 @@ struct Master {
 	if ( lane < frames ) {
 	    uint32_t fb = 0u;
 	    const FrameOut fo = frame_confidence_any_staged(&lds->mags[buf][conf_idx], h_req_mask, h_req_val, h_nbits,
-							    cnt_on ? &fb : nullptr);
+							    fb);
 	    if ( cnt_on && fb )
 		bump(MIFSK_CNT_CONF_FALLBACKS);
 	    lds->c_conf[lane] = fo.conf;
@@ -531,7 +531,7 @@ struct Master {
 	if ( lane < nq ) {
 	    uint32_t fb = 0u;
 	    const FrameOut f = frame_confidence_any_staged(&lds->mags[0][lane * cfg.n_bits],
-						cfg.req_mask[kind], cfg.req_val[kind], cfg.n_bits, cnt_on ? &fb : nullptr);
+						cfg.req_mask[kind], cfg.req_val[kind], cfg.n_bits, fb);
 	    if ( cnt_on && fb )
 		bump(MIFSK_CNT_CONF_FALLBACKS);
 	    lds->c_conf[lane] = f.conf;
@@ -689,7 +689,7 @@ struct Master {
 	f.conf = 0.0f; f.ampl = 0.0f; f.bits = 0;
 	if ( lane < zz.J - 1u ) {
 	    uint32_t fb = 0u;
-	    f = frame_confidence_any_staged(&sm[lane * nb], cfg.req_mask[0], cfg.req_val[0], nb, cnt_on ? &fb : nullptr);
+	    f = frame_confidence_any_staged(&sm[lane * nb], cfg.req_mask[0], cfg.req_val[0], nb, fb);
 	    if ( cnt_on && fb )
 		bump(MIFSK_CNT_CONF_FALLBACKS);
 	}
@@ -1356,8 +1356,11 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 	    st.noconfidence = noconfidence;
 	    st.track_amplitude = track_amplitude;
 	    st.peak_confidence = peak_confidence;
-	    st.carrier_band = -1;			// (--auto-carrier runs on the wavefront engine)
-	    st.first_band = -1;
+	    // (--auto-carrier runs on the wavefront engine: a record that engine started keeps what
+	    // it holds there, a record started here says "no band held")
+	    const bool was_started = ( rs.d_state[s].flags & MIFSK_STATE_STARTED ) != 0u;
+	    st.carrier_band = was_started ? rs.d_state[s].carrier_band : -1;
+	    st.first_band = was_started ? rs.d_state[s].first_band : -1;
 	    st.b_mark = cfg.b_mark;
 	    st.ep_b_mark = ep_b_mark;
 	    st.ep_first = ep_first;
@@ -1977,7 +1980,9 @@ static int launch_with_workers( const DevCfg &cfg, const DevCfg *d_cfg, const do
 	}
 	if ( chain_g > (uint32_t)WaveChain::kMaxGroups ) chain_g = (uint32_t)WaveChain::kMaxGroups;
 	if ( chain_g > (uint32_t)io.nstreams ) chain_g = (uint32_t)io.nstreams;
-	if ( chain_g < 1u || chain_k < 2u )
+	// (the cut is made by io.nsamples: with per-stream lengths only -- io.nsamples == 0 -- a
+	// limit of 0 would mean "all samples" to every chunk but the last; such a batch is not cut)
+	if ( chain_g < 1u || chain_k < 2u || io.nsamples == 0u )
 	    chain_g = chain_k = 0u;
     }
     const bool resumable = ( wh && wh->d_state ) || chain_g;
@@ -2025,6 +2030,7 @@ static int launch_with_workers( const DevCfg &cfg, const DevCfg *d_cfg, const do
 	    return -5;
 	mifsk_demod_io gio[WaveChain::kMaxGroups];
 	uint32_t glo[WaveChain::kMaxGroups];
+	bool prepared = true;
 	for ( uint32_t gi = 0; gi < chain_g; gi++ ) {
 	    hipStream_t gs = (hipStream_t)ch.streams[gi];
 	    // behind the caller's stream, and behind whatever the call before left on ANY group's
@@ -2051,15 +2057,16 @@ static int launch_with_workers( const DevCfg &cfg, const DevCfg *d_cfg, const do
 	    if ( io.d_status ) o.d_status = io.d_status + lo;
 	    if ( o.nstreams > 0
 		    && hipMemsetAsync(ch.d_state + lo, 0, (size_t)o.nstreams * sizeof(mifsk_stream_state), gs) != hipSuccess )
-		return -5;
+		prepared = false;		// (no early return: the caller's stream is joined below either way)
 	}
 	const uint32_t chunk = ( io.nsamples + chain_k - 1u ) / chain_k;
 	rs.append = 1u;
 	rs.d_origin = nullptr;
-	for ( uint32_t k = 0; k < chain_k; k++ ) {
+	for ( uint32_t k = 0; k < chain_k && prepared; k++ ) {
 	    const bool last = k + 1u == chain_k;
 	    rs.final = last ? 1u : 0u;
-	    rs.limit = last ? 0u : ( k + 1u ) * chunk;
+	    const uint64_t lim = (uint64_t)( k + 1u ) * chunk;
+	    rs.limit = last ? 0u : ( lim > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)lim );
 	    for ( uint32_t gi = 0; gi < chain_g; gi++ ) {
 		if ( gio[gi].nstreams <= 0 )
 		    continue;
@@ -2070,7 +2077,7 @@ static int launch_with_workers( const DevCfg &cfg, const DevCfg *d_cfg, const do
 				      (hipStream_t)ch.streams[gi]);
 	    }
 	}
-	const bool launched = hipGetLastError() == hipSuccess;
+	const bool launched = hipGetLastError() == hipSuccess && prepared;
 	for ( uint32_t gi = 0; gi < chain_g; gi++ ) {
 	    (void)hipEventRecord((hipEvent_t)ch.ev_done[gi], (hipStream_t)ch.streams[gi]);
 	    (void)hipStreamWaitEvent(st, (hipEvent_t)ch.ev_done[gi], 0);

@@ -432,7 +432,7 @@ struct Wave {
 	if ( lane < F ) {
 	    const uint32_t ci = cfg.lat_grid ? lane * ( nb - 1u ) : lane * nb;
 	    uint32_t fb = 0u;
-	    fo = frame_confidence_any(&mags[ci], cfg.req_mask[0], cfg.req_val[0], nb, cnt_on ? &fb : nullptr);
+	    fo = frame_confidence_any(&mags[ci], cfg.req_mask[0], cfg.req_val[0], nb, fb);
 	    if ( cnt_on && fb )
 		bump(MIFSK_CNT_CONF_FALLBACKS);
 	}
@@ -945,7 +945,7 @@ struct Wave {
 	    f.conf = 0.0f; f.ampl = 0.0f; f.bits = 0;
 	    if ( lane < Q ) {
 		uint32_t fb = 0u;
-		f = frame_confidence_any(&mags[lane * nb], cfg.req_mask[kind], cfg.req_val[kind], nb, cnt_on ? &fb : nullptr);
+		f = frame_confidence_any(&mags[lane * nb], cfg.req_mask[kind], cfg.req_val[kind], nb, fb);
 		if ( cnt_on && fb )
 		    bump(MIFSK_CNT_CONF_FALLBACKS);
 	    }

@@ -206,6 +206,7 @@ def test_unreadable_file_is_its_own_error_and_lengths_are_classed(gpu, tmp_path,
     bad = files[5][0]
     os.rename(bad, bad.replace("f0005", "shrunk0005"))
     files[5] = (bad.replace("f0005", "shrunk0005"),) + files[5][1:]
+    monkeypatch.setenv("MIFSK_EXPERIMENT", "1")
     monkeypatch.setenv("MIFSK_TEST_FAULT_READ", "shrunk")
     res, stats = M.demod_files(ctx, [f[0] for f in files], "1200")
     assert len(res) == len(files)

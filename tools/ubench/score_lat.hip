@@ -30,8 +30,8 @@ __global__ __launch_bounds__(64) void k_score( const float2 *gm, uint32_t nact, 
 	FrameOut f;
 	f.conf = 0.0f; f.ampl = 0.0f; f.bits = 0;
 	if ( lane < nact ) {
-	    if ( MODE == 0 ) f = frame_confidence_fixed<11>(&mags[lane * 11], req_mask, req_val);
-	    if ( MODE == 1 ) f = frame_confidence_staged<11>(&mags[lane * 11], req_mask, req_val);
+	    if ( MODE == 0 ) { uint32_t fb = 0u; f = frame_confidence_fixed<11>(&mags[lane * 11], req_mask, req_val, fb); }
+	    if ( MODE == 1 ) { uint32_t fb = 0u; f = frame_confidence_staged<11>(&mags[lane * 11], req_mask, req_val, fb); }
 	}
 	acc += f.conf + f.ampl + (float)f.bits;
 	asm volatile("" : "+v"(acc));
