@@ -576,10 +576,8 @@ void mifsk_files_free( mifsk_files *f );
 
 /* ---- transmit side (test and benchmark input generator) ------------------ */
 
-/* simpleaudio_tone_init (simple-tone-generator.c:60-89).  Kept for symmetry with the
- * reference's API only: the generator's state is per call (mifsk_tx_synthesize takes the
- * table length and the magnitude itself), so this validates `mag` and does nothing else. */
-int  mifsk_tx_tone_init( unsigned sin_table_len, float mag );
+/* (simpleaudio_tone_init, simple-tone-generator.c:60-89, has no counterpart: the generator's
+ * state is per call -- mifsk_tx_synthesize takes the table length and the magnitude itself.) */
 /* fsk_transmit_stdin + simpleaudio_tone for one stream of data words
  * (minimodem.c:81-250, simple-tone-generator.c:106-175): returns the stream's
  * length in samples (also when out is NULL or too small), or -errno */

@@ -204,7 +204,7 @@ EXPORTS = [
     "mifsk_stream_padding", "mifsk_ctx_create", "mifsk_ctx_destroy",
     "mifsk_ctx_device_name", "mifsk_abi_version", "mifsk_abi_sizeof", "mifsk_find_frame_batch", "mifsk_demod_plan_ex",
     "mifsk_demod_batch", "mifsk_demod_batch_host",
-    "mifsk_tx_tone_init", "mifsk_tx_synthesize",
+    "mifsk_tx_synthesize",
     "mifsk_databits_create", "mifsk_databits_destroy", "mifsk_databits_reset",
     "mifsk_databits_decode", "mifsk_databits_encode", "mifsk_shard_range",
     "mifsk_demod_batch_host_multi", "mifsk_demod_plan", "mifsk_stream_text",
@@ -262,8 +262,6 @@ def load():
     lib.fsk_detect_carrier.restype = C.c_int
     lib.fsk_detect_carrier.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_float]
     lib.fsk_set_tones_by_bandshift.argtypes = [C.c_void_p, C.c_uint, C.c_int]
-    lib.mifsk_tx_tone_init.restype = C.c_int
-    lib.mifsk_tx_tone_init.argtypes = [C.c_uint, C.c_float]
     lib.mifsk_tx_synthesize.restype = C.c_long
     lib.mifsk_tx_synthesize.argtypes = [C.POINTER(RxConfig), C.c_void_p, C.c_size_t,
                                         C.c_uint, C.c_float, C.c_uint, C.c_int,

@@ -1,31 +1,42 @@
-// mifsk_kernels.hip -- hand-written HIP kernels for gfx950 (MI355X / CDNA4).
+// mifsk_kernels.hip -- hand-written HIP kernels for gfx950 (MI355X / CDNA4): the receive loop
+// with ONE WORKGROUP PER STREAM (demod_kernel: a master wave and two or three worker waves),
+// the legacy single-search kernel (find_frame_kernel) and the spectrum of fsk_detect_carrier.
 //
 // The reference's FSK receive path (src/fsk.c:107-538 driven by the loop in
-// src/minimodem.c:1137-1463) restructured for a 64-wide, LDS-centred machine:
+// src/minimodem.c:1137-1463) as it is laid out here:
 //
-//  * The reference runs a full r2c FFT per bit and reads two bins.  Here a bit
-//    window is what it mathematically is: two complex dot products
+//  * The reference runs a full r2c FFT per bit and reads two bins.  Here a bit window is what
+//    it mathematically is: two complex dot products
 //        X[b] = sum_n x[n] * exp(-2 pi i b n / fftsize),  b in {mark, space}
-//    One LANE owns one bit window; the twiddle for sample n is the same for
-//    every lane, so it is fetched once per wave through the scalar cache
-//    (s_load) and each sample costs one LDS read and four f64 FMAs.
-//  * f64 accumulation in index order, exactly the operation sequence of the
-//    oracle, so results are bit-identical to it (the "-P" reference tests need
-//    the off-tone bin below FLT_EPSILON, which f32 accumulation cannot
-//    guarantee).
-//  * Audio is staged once, coalesced (16 B per lane), from HBM into an LDS
-//    slab.  The slab is row-skewed (one pad word per bit length) so that 64
-//    lanes striding by one bit length hit 64 different banks.
-//  * The receive loop is a serial, data-dependent cursor.  A workgroup owns a
-//    stream; whenever it must evaluate a search it also evaluates, with the
-//    otherwise idle lanes, the first-try position of the next M frames (where
-//    the cursor will land if every frame locks at its expected offset -- the
-//    normal case once carrier is acquired).  Those results sit in an LDS cache
-//    keyed by absolute position; later iterations hit the cache and replay the
-//    reference's decision logic without touching the samples again.  A miss
-//    simply recomputes: results never depend on what was predicted.
+//    One LANE owns one bit window.  The twiddle table is spread over the lanes of each 16-lane
+//    row (three groups of 16 entries resident in VGPRs in the Bell-202 instantiation) and
+//    `v_fmac_f64_dpp ... row_newbcast:J` broadcasts entry J and does the FMA in one
+//    instruction (mifsk_devlib.h): a sample costs one convert and four of these.
+//  * f64 accumulation in index order, exactly the operation sequence of the oracle, so results
+//    are bit-identical to it (the reference's "-P" tests need the off-tone bin below
+//    FLT_EPSILON, which f32 accumulation cannot guarantee).
+//  * The receive loop is a serial, data-dependent cursor, so the stream's workgroup is a
+//    two-stage pipeline.  While carrier is held the next frame is first looked for exactly
+//    lock_advance samples after the last and that try is accepted whenever it reaches the
+//    search limit: the positions that will be asked for lie on a LATTICE.  The WORKERS turn
+//    audio into magnitudes for a batch of consecutive lattice frames -- each stages the span
+//    of its 64 windows as 64 x 10 consecutive float4 (unaligned 16-byte global loads into
+//    registers, the next round already in flight, then ds_write_b128 into a private, unskewed
+//    LDS region) and correlates one window per lane -- while the MASTER scores the batch
+//    before (one lane per frame), replays the reference's acceptance predicates and f32
+//    state recurrences over it in frame order as a DPP lane scan, and writes the outputs.
+//    One LDS-only barrier per batch connects them (a two-slot command block).
+//  * Whatever leaves the lattice -- acquisition, a frame that fails a predicate -- goes through
+//    SCAN: fsk_find_frame at one cursor, every candidate of the zig-zag evaluated by all
+//    waves from a row-skewed LDS slab.  The carrier-held fine rescan of a frame the lattice had
+//    already scored (minimodem.c:1357-1389) is run by the master alone (solo_fine): one pass
+//    of two windows per lane from a coalesced sweep into the free magnitude buffer, scores and
+//    the reference's selection (a DPP argmax) in registers, the workers undisturbed.
+//  * Nothing ever depends on the speculation being right: a frame that fails any predicate is
+//    recomputed from the samples.
 //
-// No MFMA: the path is HBM-bound (4 B read per sample, ~5 f64 FMA per sample).
+// No MFMA: the path is bound by HBM reads (4 B per sample) and by the length of each stream's
+// serial chain, not by a dense contraction.
 #include <hip/hip_runtime.h>
 #include <cfloat>
 #include <cmath>

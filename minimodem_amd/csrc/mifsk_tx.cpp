@@ -86,14 +86,6 @@ struct ToneGen {
 
 } // namespace
 
-extern "C" int mifsk_tx_tone_init( unsigned table_len, float mag )
-{
-    // kept for ABI symmetry with simpleaudio_tone_init(); the generator state
-    // is per call (mifsk_tx_synthesize), nothing global to initialise
-    (void)table_len;
-    return mag > 0.0f ? 0 : -EINVAL;
-}
-
 // Synthesize one stream.  `words` are the data words (what the databits
 // encoder would have produced: bytes for ascii, 5-bit codes for baudot).
 // Returns the number of samples the stream has (also when out == NULL or

@@ -293,8 +293,12 @@ ofsk_detect_carrier( ofsk_plan *p, const float *samples, unsigned int nsamples,
     if ( nsamples > (unsigned int)p->fftsize )	/* assert in the reference (fsk.c:547) */
 	return -1;
     const unsigned int N = p->fftsize;
-    static double *cs;			/* table of the last fftsize (test infrastructure: one thread) */
-    static unsigned int cs_n;
+    /* table of the last fftsize, one per thread: ofsk_rx_stream is called from many threads at
+     * once (tests/_oracle.py oracle_batch_mismatches, tools/soak.py), and a table shared between
+     * them was freed and rebuilt by two threads at the same time at the first --auto-carrier
+     * mode of a soak run (round 5: one run in 108 died of a corrupted heap in the CHECKER) */
+    static __thread double *cs;
+    static __thread unsigned int cs_n;
     if ( cs_n != N ) {
 	free(cs);
 	cs = malloc(sizeof(double) * 2 * N);

@@ -147,7 +147,7 @@ def main():
                           % (mode, kw, i, len(streams[i]), n, nref))
                 nf += n
         total_frames += nf
-        print("%-6s %-40s %4d streams %7d frames  %.1f s%s" % (mode, kw, len(streams), nf, time.time() - t, cut))
+        print("%-6s %-40s %4d streams %7d frames  %.1f s%s" % (mode, kw, len(streams), nf, time.time() - t, cut), flush=True)
     print("seed %d (%s engine, %s addressing%s): %d frames compared, %d mismatching streams"
           % (args.seed, args.engine, "ring" if args.ring else "flat",
              ", %d slabs per stream" % args.slabs if args.slabs else

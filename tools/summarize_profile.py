@@ -73,6 +73,15 @@ def main():
     configs = sys.argv[2:] or ["1200"]
     dst = os.path.join(ROOT, "profiles")
     ksid = bench.kernel_source_id()
+    # the code objects' own register / spill / scratch figures, made NOW from the sources the
+    # summaries are stamped with (kernel_source_id): a resources file left from before the last
+    # kernel change would contradict the counters next to it
+    import subprocess
+    res = os.path.join(dst, "%s_kernel_resources.txt" % tag)
+    with open(res, "w") as f:
+        f.write("# kernel_source_id %s\n" % ksid)
+        f.flush()
+        subprocess.run(["bash", os.path.join(ROOT, "tools", "kernel_resources.sh")], stdout=f, check=True)
     for c in configs:
         src = os.path.join(ROOT, "gpurun_out", "profile_%s_%s" % (tag, c))
         pre = "%s_%s" % (tag, c)
