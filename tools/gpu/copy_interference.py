@@ -5,7 +5,8 @@ through RCCL copy kernels while its own demod kernel runs (configs[3]: 7 x 19.7 
 step; configs[1]: 7 x 1.2 MB per 0.45 ms).  Here: the config's kernel alone, then with a
 device-to-device copy of that many bytes per step running concurrently on a second stream -- a
 plain torch copy kernel, which takes as many CUs as it likes: an upper bound on what RCCL's few
-channel workgroups do."""
+channel workgroups do.  Round 5: also as SEVEN copies on seven streams (one per peer, each a
+peer's share), which is how the grouped irecv's arrive: seven concurrent kernels instead of one."""
 import os, sys, json
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -30,6 +31,8 @@ for name in ("1200", "12000"):
     src = torch.empty(gather_bytes, dtype=torch.uint8, device="cuda")
     dst = torch.empty_like(src)
     side = torch.cuda.Stream()
+    peers = [torch.cuda.Stream() for _ in range(7)]
+    per_peer = gather_bytes // 7
     res = M.demod_batch(ctx, cfg, x, nsamples=lens, want=("bytes",))
     torch.cuda.synchronize()
 
@@ -38,10 +41,15 @@ for name in ("1200", "12000"):
         for _ in range(reps):
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize()
-            if with_copy:
+            if with_copy == 1:
                 with torch.cuda.stream(side):
                     for _ in range(2):          # (keeps copying while the kernel runs)
                         dst.copy_(src)
+            elif with_copy == 7:
+                for k, st in enumerate(peers):
+                    with torch.cuda.stream(st):
+                        for _ in range(2):
+                            dst[k * per_peer:(k + 1) * per_peer].copy_(src[k * per_peer:(k + 1) * per_peer])
             e0.record()
             M.demod_batch(ctx, cfg, x, nsamples=lens, want=("bytes",), out=res)
             e1.record()
@@ -49,10 +57,12 @@ for name in ("1200", "12000"):
             ts.append(e0.elapsed_time(e1))
         return float(np.median(ts))
 
-    alone = run(False)
-    shared = run(True)
+    alone = run(0)
+    shared = run(1)
+    seven = run(7)
     out[name] = {"kernel_ms_alone": alone, "kernel_ms_beside_copy": shared, "slowdown": shared / alone,
-                 "copy_bytes_per_step": gather_bytes}
+                 "kernel_ms_beside_7_copies": seven, "slowdown_7_streams": seven / alone,
+                 "copy_bytes_per_step": gather_bytes, "bytes_per_peer": per_peer}
     print(name, json.dumps(out[name]), flush=True)
     del x, src, dst
     torch.cuda.empty_cache()
