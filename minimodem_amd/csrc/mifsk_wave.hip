@@ -487,6 +487,35 @@ struct Wave {
 	    }
 	    return;
 	}
+	// (instantiations for one short bit length -- 12000 baud's runs at 128 VGPRs with eight
+	// spilled and searches four times per stream -- are left as they were)
+	if ( NQ <= 0 && cfg.skew == 0u ) {
+	    // A slab without pad words (SAME: the host found that padding spreads no banks) is the
+	    // stream itself: row 0 is put at the float4 boundary below `lo` -- the caller sets slab_lo
+	    // to it (plain_slab_origin) -- and a vector is ONE aligned ds_write_b128, samples at or
+	    // beyond N zeroed; the per-sample row arithmetic of store4_skewed (a divide by the bit
+	    // length and four scalar stores per vector: ~75 VALU instructions per float4, 300 per
+	    // fine scan of SAME, whose kernel is bound by VALU issue) is for padded slabs only.
+	    for ( uint32_t v0 = 0; v0 < nvec; v0 += 64u * SV ) {
+		float4 buf[SV];
+#pragma unroll
+		for ( int i = 0; i < SV; i++ ) {
+		    const uint32_t v = v0 + i * 64 + lane;
+		    if ( v0 + i * 64 < nvec )
+			buf[i] = load4_raw(x, org4 + ( v << 2 ), N);
+		}
+#pragma unroll
+		for ( int i = 0; i < SV; i++ ) {
+		    const uint32_t v = v0 + i * 64 + lane;
+		    if ( v0 + i * 64 < nvec && v < nvec ) {
+			const uint32_t a = org4 + ( v << 2 );
+			const float4 sv = ( a + 3u < N && a + 3u >= a ) ? buf[i] : mask4(buf[i], a, N);
+			*reinterpret_cast<float4 *>(slab + ( v << 2 )) = sv;
+		    }
+		}
+	    }
+	    return;
+	}
 	for ( uint32_t v0 = 0; v0 < nvec; v0 += 64u * SV ) {
 	    float4 buf[SV];
 #pragma unroll
@@ -502,6 +531,14 @@ struct Wave {
 		    store4_skewed(cfg, slab, g.slab_cap, v << 2, head, buf[i], org4 + ( v << 2 ), N);
 	    }
 	}
+    }
+
+    // where row 0 of the slab lies after stage_slab(base, lo, n)
+    __device__ __forceinline__ uint32_t plain_slab_origin( uint32_t lo ) const
+    {
+	if ( NQ <= 0 && cfg.skew == 0u && !ring )
+	    return lo & ~3u;
+	return lo;
     }
 
     // correlate candidates c0 .. c0+Q of `zz` at cursor base into mags[q * n_bits + k]
@@ -902,7 +939,7 @@ struct Wave {
 		// search reads and no more.
 		const uint32_t need = ( hi - lo + 7u ) & ~3u;
 		const uint32_t take = ( carrier_held || ring ) ? need : g.slab_cap;
-		slab_lo = lo;
+		slab_lo = plain_slab_origin(lo);
 		slab_hi = lo + take;
 		drop_prefetch();		// (the cursor left the lattice)
 		stage_slab(base, lo, take);
@@ -965,6 +1002,26 @@ struct Wave {
 	    }
 	    // fsk.c:492-501 over the chunk, in scan order on lane values
 	    uint32_t win = ~0u;
+	    if ( NQ <= 0 && r.conf < limit ) {
+		// While the best so far is below the limit, the loop below ends at the FIRST candidate
+		// that reaches the limit (it necessarily beats everything tried before it); if none
+		// does, the winner is the first candidate attaining the chunk's maximum, provided
+		// that exceeds the best so far (strict >; a NaN never wins).  Two ballots and a DPP
+		// maximum instead of a readlane / compare / branch round trip per candidate.
+		const bool cand = lane < Q && f.conf == f.conf;
+		const unsigned long long hit = __ballot(cand && f.conf >= limit);
+		if ( hit ) {
+		    win = (uint32_t)__ffsll((long long)hit) - 1u;
+		    r.conf = lane_bcast(f.conf, win);
+		    done = true;
+		} else {
+		    const float best = wave_max_f32(cand ? f.conf : -INFINITY);
+		    if ( r.conf < best ) {
+			win = (uint32_t)__ffsll((long long)__ballot(cand && f.conf == best)) - 1u;
+			r.conf = best;
+		    }
+		}
+	    } else
 	    for ( uint32_t i = 0; i < Q; i++ ) {
 		const float c = lane_bcast(f.conf, i);
 		if ( r.conf < c ) {
