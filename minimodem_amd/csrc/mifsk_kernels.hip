@@ -1287,6 +1287,31 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 	    }
 	}
 
+	advance = frame_start + h_fn - h_overscan;			// minimodem.c:1407
+
+	// (first of all, so that the workers' first round on a moved lattice is under way while
+	// this wave does the frame's bookkeeping and outputs)
+	// carrier is held: (re)start the lattice pipeline where the next
+	// iteration will search first, unless a matching batch is already in
+	// flight or already scored
+	if ( ctx.lat_batch && advance <= N - base ) {
+	    const uint32_t p = base + advance + h_first1;
+	    const bool cached = ctx.lattice_lookup(p) != ~0u;
+	    const uint32_t t_ls = MIFSK_CLOCK();
+	    if ( ctx.pause ) {
+		ctx.pause--;			// the lattice kept missing: plain searches for a while
+	    } else if ( !cached && !( ctx.inflight && ctx.inflight_anchor == p ) ) {
+		ctx.give_up();			// (a batch left running by a rescan that moved the cursor)
+		if ( ctx.cold >= 4u ) {
+		    ctx.cold = 0;
+		    ctx.pause = 32;
+		} else {
+		    ctx.lattice_start(p);
+		}
+	    }
+	    cyc_restart += MIFSK_CLOCK() - t_ls;
+	}
+
 	track_amplitude = ( track_amplitude + amplitude ) / 2.0f;	// minimodem.c:1391-1400
 	if ( peak_confidence < confidence )
 	    peak_confidence = confidence;
@@ -1294,8 +1319,6 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 	amplitude_total += amplitude;
 	nframes_decoded++;
 	noconfidence = 0;
-
-	advance = frame_start + h_fn - h_overscan;			// minimodem.c:1407
 
 	bits = ( bits >> h_dshift ) & h_dmask;				// data_bits_of(), minimodem.c:1415-1428
 	if ( h_msb )
@@ -1327,26 +1350,6 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 	if ( !suppressed )
 	    n_out_bytes++;
 
-	// carrier is held: (re)start the lattice pipeline where the next
-	// iteration will search first, unless a matching batch is already in
-	// flight or already scored
-	if ( ctx.lat_batch && advance <= N - base ) {
-	    const uint32_t p = base + advance + h_first1;
-	    const bool cached = ctx.lattice_lookup(p) != ~0u;
-	    const uint32_t t_ls = MIFSK_CLOCK();
-	    if ( ctx.pause ) {
-		ctx.pause--;			// the lattice kept missing: plain searches for a while
-	    } else if ( !cached && !( ctx.inflight && ctx.inflight_anchor == p ) ) {
-		ctx.give_up();			// (a batch left running by a rescan that moved the cursor)
-		if ( ctx.cold >= 4u ) {
-		    ctx.cold = 0;
-		    ctx.pause = 32;
-		} else {
-		    ctx.lattice_start(p);
-		}
-	    }
-	    cyc_restart += MIFSK_CLOCK() - t_ls;
-	}
 	cyc_general += MIFSK_CLOCK() - t_gen;
     }
 
