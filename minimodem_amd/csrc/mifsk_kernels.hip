@@ -378,6 +378,15 @@ struct Master {
     // what the steady state reads of the configuration at every batch, read once (keep_scalar)
     uint32_t		h_la, h_la_magic, h_nbits;
     uint64_t		h_req_mask, h_req_val;
+    TwGroup		mtg[3];		// the table's first groups, resident (solo_fine)
+
+    template <int NG>
+    __device__ __forceinline__ void keep_groups()
+    {
+#pragma unroll
+	for ( int gi = 0; gi < NG; gi++ )
+	    mtg[gi] = tw_group_load(tw, (uint32_t)gi, lane);
+    }
 
     __device__ __forceinline__ Master( const DevCfg &c, const double *t, const float *xs,
 	    uint32_t n, StreamLds *l, uint32_t cap, uint32_t lf, uint32_t lat_round )
@@ -602,10 +611,7 @@ struct Master {
 	    if ( h0 ) *reinterpret_cast<float4 *>(sbuf + 4u * lane) = make_float4(v0.x, v0.y, v0.z, v0.w);
 	    if ( h1 ) *reinterpret_cast<float4 *>(sbuf + 4u * ( lane + 64u )) = make_float4(v1.x, v1.y, v1.z, v1.w);
 	}
-	TwGroup tg[3];
-#pragma unroll
-	for ( int gi = 0; gi < ( NQ + 3 ) / 4; gi++ )
-	    tg[gi] = tw_group_load(tw, (uint32_t)gi, lane);
+	const TwGroup (&tg)[3] = mtg;	// (resident: 24 registers against six LDS loads per rescan)
 	wave_lds_sync();
 #ifdef MIFSK_PROFILE
 	asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -883,6 +889,8 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
     const bool t0 = lane == 0;
 
     Master<USE_SLAB> ctx(cfg, tw, x, N, lds, slab_cap, lat_frames, lat_round);
+    if constexpr ( NQ > 0 )
+	ctx.template keep_groups<( NQ + 3 ) / 4>();
     // What the bulk path below reads of the configuration for every batch of lattice frames,
     // read once (keep_scalar): left as cfg.x the compiler re-loads each at every use -- a dozen
     // s_load + s_waitcnt round trips through the scalar cache per batch, in the one wave whose
