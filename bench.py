@@ -444,6 +444,24 @@ def timed_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, 
                 wait_all(pending[b])
                 pending[b] = None
 
+    # Before the contract's W warm-up passes: bring the GPU out of its idle state.  A pass of
+    # configs[1] is 0.45 ms and the driver's W = 5, K = 20 is 11 ms after seconds of host-side
+    # set-up: the first two dozen launches after idling run 6-8 % slower than every later one
+    # (same box, same process: K = 20 -> 0.450-0.457 ms per launch, K = 200 -> 0.4239,
+    # profiles/r05_history.md section 5).  Untimed, kernel only (no gather), disclosed in the line.
+    preheat = {"ms": 0.0, "launches": 0}
+    if args.preheat_ms > 0 and failure[0] is None:
+        tp = time.perf_counter()
+        try:
+            while (time.perf_counter() - tp) * 1e3 < args.preheat_ms and preheat["launches"] < 4096:
+                for _ in range(8):
+                    M.demod_batch(ctx, cfg, samples, out=bufs[preheat["launches"] & 1], **kw)
+                    preheat["launches"] += 1
+                torch.cuda.synchronize()
+        except Exception as e:			# noqa: BLE001
+            failure[0] = e
+        preheat["ms"] = (time.perf_counter() - tp) * 1e3
+
     for i in range(warmup):
         step(i)
     drain()
@@ -453,11 +471,20 @@ def timed_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, 
     torch.cuda.synchronize()
     wait_s[0] = 0.0
 
+    # HIP events on the launch stream: ONE pair around the K launches (average launch duration =
+    # elapsed / K, the gaps between launches included), or with --step-events a pair around
+    # every launch (the per-launch spread, at the price of a signal packet between launches:
+    # +7 us per step on configs[1])
+    region = not args.step_events
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-           for _ in range(steps)]
+           for _ in range(1 if region else steps)]
     t0 = time.perf_counter()
+    if region:
+        evs[0][0].record()
     for i in range(steps):
-        step(i, evs[i])
+        step(i, None if region else evs[i])
+    if region:
+        evs[0][1].record()
     drain()
     torch.cuda.synchronize()
     if dist is not None:
@@ -469,6 +496,8 @@ def timed_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, 
     agree(torch, dist, failure[0], "%s: timed loop" % name)
 
     kernel_ms = [a.elapsed_time(b) for a, b in evs]
+    if region:
+        kernel_ms = [kernel_ms[0] / max(1, steps)] * steps
     total_samples = total_samples_local
     per_rank = None
     if dist is not None:
@@ -590,9 +619,12 @@ def timed_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, 
                          "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": hbm_traffic(name),
                          "kernel": launch["kernel"], "launch": launch,
                          "kernel_ms_avg": kavg * 1e3, "kernel_ms_min": float(np.min(kernel_ms)),
+                         "events": "one pair around the K launches" if not args.step_events else "a pair per launch",
                          "algorithmic_bytes_per_launch": total_samples_local * 4.0},
             "payload_roundtrip_ok_streams": "%d/%d" % (ok_streams, judged),
             "device": ctx.device_name,
+            "preheat": {"untimed_launches_before_warmup": preheat["launches"], "ms": preheat["ms"],
+                        "why": "the first launches after host-side set-up run at idle clocks"},
         }
         if by_condition is not None:
             line["payload_by_condition"] = by_condition
@@ -739,6 +771,10 @@ def main():
                     help="skip the CPU legs (the timed baselines and the whole-batch oracle verdict)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the H2D-inclusive leg")
     ap.add_argument("--no-extra", action="store_true", help="configs[1] only: skip configs[2..4]")
+    ap.add_argument("--preheat-ms", type=float, default=300.0,
+                    help="untimed kernel launches before the W warm-up passes (0 = none)")
+    ap.add_argument("--step-events", action="store_true",
+                    help="an event pair around every launch instead of one around the K launches")
     ap.add_argument("--engine", default=None, choices=["wave", "workgroup"],
                     help="force a receive-loop engine (default: the library chooses)")
     args = ap.parse_args()

@@ -36,30 +36,34 @@ for name in ("1200", "12000"):
     res = M.demod_batch(ctx, cfg, x, nsamples=lens, want=("bytes",))
     torch.cuda.synchronize()
 
-    def run(with_copy, reps=12):
-        ts = []
-        for _ in range(reps):
-            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize()
-            if with_copy == 1:
-                with torch.cuda.stream(side):
-                    for _ in range(2):          # (keeps copying while the kernel runs)
-                        dst.copy_(src)
-            elif with_copy == 7:
-                for k, st in enumerate(peers):
-                    with torch.cuda.stream(st):
-                        for _ in range(2):
-                            dst[k * per_peer:(k + 1) * per_peer].copy_(src[k * per_peer:(k + 1) * per_peer])
-            e0.record()
-            M.demod_batch(ctx, cfg, x, nsamples=lens, want=("bytes",), out=res)
-            e1.record()
-            torch.cuda.synchronize()
-            ts.append(e0.elapsed_time(e1))
-        return float(np.median(ts))
+    def once(with_copy):
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        if with_copy == 1:
+            with torch.cuda.stream(side):
+                for _ in range(2):          # (keeps copying while the kernel runs)
+                    dst.copy_(src)
+        elif with_copy == 7:
+            for k, st in enumerate(peers):
+                with torch.cuda.stream(st):
+                    for _ in range(2):
+                        dst[k * per_peer:(k + 1) * per_peer].copy_(src[k * per_peer:(k + 1) * per_peer])
+        e0.record()
+        M.demod_batch(ctx, cfg, x, nsamples=lens, want=("bytes",), out=res)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1)
 
-    alone = run(0)
-    shared = run(1)
-    seven = run(7)
+    # (out of the idle state first -- the launches after a pause run 6-8 % slower, bench.py's
+    # preheat -- then the three variants in turn, so that what drift is left is shared)
+    for _ in range(400 if name == "1200" else 150):
+        M.demod_batch(ctx, cfg, x, nsamples=lens, want=("bytes",), out=res)
+    torch.cuda.synchronize()
+    ts = {0: [], 1: [], 7: []}
+    for _ in range(16):
+        for mode_ in (0, 1, 7):
+            ts[mode_].append(once(mode_))
+    alone, shared, seven = (float(np.median(ts[k])) for k in (0, 1, 7))
     out[name] = {"kernel_ms_alone": alone, "kernel_ms_beside_copy": shared, "slowdown": shared / alone,
                  "kernel_ms_beside_7_copies": seven, "slowdown_7_streams": seven / alone,
                  "copy_bytes_per_step": gather_bytes, "bytes_per_peer": per_peer}
