@@ -36,6 +36,7 @@ Prints ONE JSON line on rank 0 (contract in the task description), including
                  full batch (1200) or a bounded sample, output compared with the GPU's
 """
 import argparse
+import contextlib
 import hashlib
 import json
 import os
@@ -268,6 +269,9 @@ def agree(torch, dist, err, what):
         raise RankFailed("%s: %s" % (what, repr(err) if err is not None else "another rank failed"))
 
 
+_LANES = {}
+
+
 def run_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, cpu_leg, oracle_leg=True):
     """One BASELINE entry on this rank's shard: synthesize the batch on the device (or host for
     configs[1]), W untimed + K timed passes bracketed by barrier + synchronize, kernel time by
@@ -302,13 +306,27 @@ def run_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, cp
     frames_cap = M.max_frames(cfg, stride)
     want = ("bytes",)
     kw = dict(want=want, frames_cap=frames_cap, nsamples=lens, engine=args.engine, episodes_cap=8)
+    # Passes in flight (--pipeline P): pass i runs on stream i mod P with its own context (each
+    # context owns its launch scratch) and its own output set, so that pass i + 1 fills the CUs
+    # that pass i's late streams leave idle (a launch ends ~20 % after its mean stream on
+    # configs[1], and long after it under impairments: DESIGN.md section 6).
+    pipe = max(1, int(args.pipeline))
+    lanes = None
     try:
-        bufs = [M.demod_batch(ctx, cfg, samples, **kw) for _ in range(2)]
+        # (made once per process and shared by the workloads: HIP multiplexes streams onto a few
+        # hardware queues, and lanes created anew for every workload end up sharing one)
+        if pipe not in _LANES:
+            _LANES[pipe] = ([ctx] + [M.Context(torch.cuda.current_device()) for _ in range(pipe - 1)],
+                            [None] if pipe == 1 else [torch.cuda.Stream() for _ in range(pipe)])
+        ctxs, streams = _LANES[pipe]
+        bufs = [M.demod_batch(ctxs[k % pipe], cfg, samples, stream=streams[k % pipe], **kw)
+                for k in range(max(2, pipe))]
+        lanes = (ctxs, streams)
         torch.cuda.synchronize()
     except Exception as e:				# noqa: BLE001
         setup_err = e
     agree(torch, dist, setup_err, "%s: first launch" % name)
-    return timed_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, cpu_leg, oracle_leg,
+    return timed_workload(name, args, M, torch, dist, ctx, lanes, rank, world, steps, warmup, cpu_leg, oracle_leg,
                           cfg, mode, entry, samples, lens, bufs, kw, payloads, lo, nstreams, nsamp, stride,
                           frames_cap, total_streams, total_samples_local)
 
@@ -403,15 +421,18 @@ def work_counters(name, M, torch, ctx, cfg, samples, lens, kw):
         return None
 
 
-def timed_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, cpu_leg, oracle_leg,
+def timed_workload(name, args, M, torch, dist, ctx, lanes, rank, world, steps, warmup, cpu_leg, oracle_leg,
                    cfg, mode, entry, samples, lens, bufs, kw, payloads, lo, nstreams, nsamp, stride,
                    frames_cap, total_streams, total_samples_local):
-    pending = [None, None]
+    ctxs, streams = lanes
+    pipe = len(ctxs)
+    nbuf = len(bufs)				# = max(2, pipe): pass i writes set i mod nbuf
+    pending = [None] * nbuf
     # what a stream can decode at most is known on the host (its length): the gather ships
     # that many columns, not the whole frames_cap-wide buffer
     cols = int(M.max_frames(cfg, nsamp if lens is None else int(lens.max())))
     rows = [M.shard_range(total_streams, r, world)[1] - M.shard_range(total_streams, r, world)[0] for r in range(world)]
-    gatherer = M.ByteGatherer(dist, rank, world, cols=min(cols, frames_cap), rows=rows)
+    gatherer = M.ByteGatherer(dist, rank, world, cols=min(cols, frames_cap), rows=rows, slots=nbuf)
     failure = [None]
     wait_s = [0.0]
 
@@ -421,25 +442,33 @@ def timed_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, 
             w.wait()
         wait_s[0] += time.perf_counter() - t
 
+    issued = [0]
+
     def step(i, events=None):
-        b = i & 1
-        if pending[b] is not None:		# its buffers are about to be overwritten
-            wait_all(pending[b])
-            pending[b] = None
-        if events is not None:
-            events[0].record()
-        try:
-            M.demod_batch(ctx, cfg, samples, out=bufs[b], **kw)
-        except Exception as e:			# noqa: BLE001 -- this rank still joins every gather
-            failure[0] = failure[0] or e
-        if events is not None:
-            events[1].record()
-        if world > 1:
-            # decoded bytes -> rank 0, grouped send/recv (each peer uses its own xGMI link)
-            pending[b] = gatherer.start(bufs[b]["bytes"], bufs[b]["nbytes"])
+        b = i % nbuf
+        lane = i % pipe
+        # (everything of this pass is ordered on its lane's stream: the wait for the gather
+        # that last read this output set, the launch, the next gather's sends)
+        with torch.cuda.stream(streams[lane]) if streams[lane] is not None else contextlib.nullcontext():
+            if pending[b] is not None:		# its buffers are about to be overwritten
+                wait_all(pending[b])
+                pending[b] = None
+            if events is not None:
+                events[0].record()
+            try:
+                M.demod_batch(ctxs[lane], cfg, samples, stream=streams[lane], out=bufs[b], **kw)
+            except Exception as e:		# noqa: BLE001 -- this rank still joins every gather
+                failure[0] = failure[0] or e
+            if events is not None:
+                events[1].record()
+            if world > 1:
+                # decoded bytes -> rank 0, grouped send/recv (each peer uses its own xGMI link)
+                pending[b] = gatherer.start(bufs[b]["bytes"], bufs[b]["nbytes"])
+        issued[0] = i + 1
 
     def drain():
-        for b in (0, 1):
+        for k in range(nbuf):			# oldest first
+            b = (issued[0] + k) % nbuf
             if pending[b] is not None:
                 wait_all(pending[b])
                 pending[b] = None
@@ -462,6 +491,22 @@ def timed_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, 
             failure[0] = e
         preheat["ms"] = (time.perf_counter() - tp) * 1e3
 
+    # With passes in flight on several streams no event pair brackets "a launch": the kernel's own
+    # average duration is taken here, from K launches on ONE stream between the preheat and the
+    # warm-up passes (untimed by the contract) -- the figure the rocprofv3 summary under profiles/
+    # is compared with -- and the K timed passes below are timed by the contract's clock alone.
+    serial_evs = None
+    if pipe > 1:
+        serial_evs = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        try:
+            serial_evs[0].record()		# (torch's current stream, where ctx launches by default)
+            for i in range(steps):
+                M.demod_batch(ctx, cfg, samples, out=bufs[0], **kw)
+            serial_evs[1].record()
+            torch.cuda.synchronize()
+        except Exception as e:			# noqa: BLE001
+            failure[0] = failure[0] or e
+
     for i in range(warmup):
         step(i)
     drain()
@@ -475,15 +520,15 @@ def timed_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, 
     # elapsed / K, the gaps between launches included), or with --step-events a pair around
     # every launch (the per-launch spread, at the price of a signal packet between launches:
     # +7 us per step on configs[1])
-    region = not args.step_events
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-           for _ in range(1 if region else steps)]
+    region = not args.step_events or pipe > 1
+    evs = [serial_evs] if pipe > 1 else [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                                         for _ in range(1 if region else steps)]
     t0 = time.perf_counter()
-    if region:
+    if region and pipe == 1:
         evs[0][0].record()
     for i in range(steps):
         step(i, None if region else evs[i])
-    if region:
+    if region and pipe == 1:
         evs[0][1].record()
     drain()
     torch.cuda.synchronize()
@@ -517,7 +562,7 @@ def timed_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, 
                     "gather_wait_ms_per_step": [float(a[2]) for a in allr],
                     "gather_bytes_per_peer_per_step": gatherer.bytes_per_peer(nstreams)}
 
-    last = (steps - 1) & 1 if steps else 0
+    last = (steps - 1) % nbuf if steps else 0
     res = M.results_to_host(bufs[last])
     gpu_bytes, gpu_nbytes = res["bytes"], res["nbytes"]
 
@@ -619,10 +664,18 @@ def timed_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, 
                          "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": hbm_traffic(name),
                          "kernel": launch["kernel"], "launch": launch,
                          "kernel_ms_avg": kavg * 1e3, "kernel_ms_min": float(np.min(kernel_ms)),
-                         "events": "one pair around the K launches" if not args.step_events else "a pair per launch",
+                         "events": ("one pair around K launches on one stream, between the preheat and the warm-up passes"
+                                    if pipe > 1 else "one pair around the K launches" if not args.step_events
+                                    else "a pair per launch"),
                          "algorithmic_bytes_per_launch": total_samples_local * 4.0},
             "payload_roundtrip_ok_streams": "%d/%d" % (ok_streams, judged),
             "device": ctx.device_name,
+            "pipeline": {"passes_in_flight": pipe, "streams": pipe,
+                         "ms_per_pass": dt / steps * 1e3,
+                         "hbm_frac_of_the_timed_passes": total_samples_local * 4.0 * steps / dt / HBM_PEAK,
+                         "note": "pass i runs on stream i mod P (own context, own outputs): it fills the CUs "
+                                 "the late streams of pass i - 1 leave idle; roofline.* is the kernel launched "
+                                 "serially on one stream"},
             "preheat": {"untimed_launches_before_warmup": preheat["launches"], "ms": preheat["ms"],
                         "why": "the first launches after host-side set-up run at idle clocks"},
         }
@@ -771,6 +824,8 @@ def main():
                     help="skip the CPU legs (the timed baselines and the whole-batch oracle verdict)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the H2D-inclusive leg")
     ap.add_argument("--no-extra", action="store_true", help="configs[1] only: skip configs[2..4]")
+    ap.add_argument("--pipeline", type=int, default=3,
+                    help="passes in flight: pass i is launched on stream i mod P (1 = one stream)")
     ap.add_argument("--preheat-ms", type=float, default=300.0,
                     help="untimed kernel launches before the W warm-up passes (0 = none)")
     ap.add_argument("--step-events", action="store_true",
@@ -833,13 +888,14 @@ def main():
     line = run_workload(name, args, M, torch, dist, ctx, rank, world, args.steps, args.warmup,
                         cpu_leg=not args.no_cpu, oracle_leg=not args.no_cpu)
     if args.config is None and not args.no_extra:
-        # the other BASELINE entries at their stated per-GPU sizes, a few timed passes each, device
+        # the other BASELINE entries at their stated per-GPU sizes, the same K and W (with passes in
+        # flight a handful of passes would mostly measure the pipeline filling and draining), device
         # generator, no CPU leg: driver-visible kernel time and roofline fraction per entry
         extra = {}
         for other in ("1200noise", "12000", "same", "rtty"):	# (shortest kernels first, the 12 ms one last)
             try:
                 sub = run_workload(other, args, M, torch, dist, ctx, rank, world,
-                                   max(1, min(5, args.steps)), 1, cpu_leg=False,
+                                   args.steps, args.warmup, cpu_leg=False,
                                    oracle_leg=not args.no_cpu)
             except RankFailed as e:
                 # (raised on EVERY rank by agree(): nobody is left inside a collective)
@@ -858,6 +914,8 @@ def main():
                     "roofline": {"bound": "hbm", "achieved": rf["achieved"], "peak": rf["peak"],
                                  "unit": rf["unit"], "frac": rf["frac"], "traffic": rf["traffic"]},
                     "launch": rf["launch"],
+                    "pipeline": {k: sub["pipeline"][k] for k in ("passes_in_flight", "ms_per_pass",
+                                                                 "hbm_frac_of_the_timed_passes")},
                     "payload_roundtrip_ok_streams": sub["payload_roundtrip_ok_streams"],
                     "oracle_mismatching_streams": sub.get("oracle_mismatching_streams"),
                     "oracle": sub.get("oracle"),

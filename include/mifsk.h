@@ -288,7 +288,10 @@ typedef struct mifsk_demod_io {
 /* Asynchronous on `stream`: the outputs are complete when `stream` reaches the point
  * behind the call.  (A large wavefront-engine batch is run as several launches on
  * streams of the context's own, forked from and joined back into `stream` with events --
- * mifsk_launch_info.chain_groups below; nothing changes for the caller.) */
+ * mifsk_launch_info.chain_groups below; nothing changes for the caller.)  Calls on ONE
+ * context are ordered by the caller (a context owns its launch scratch); to keep several
+ * batches in flight -- a launch ends well after its mean stream, so the next one fills the
+ * chip -- give each stream a context of its own (INTEGRATION.md 2a', bench.py --pipeline). */
 int mifsk_demod_batch( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
 	const mifsk_demod_io *io, void *stream );
 

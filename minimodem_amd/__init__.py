@@ -376,23 +376,24 @@ class ByteGatherer:
     tests) -- and returns the work handles; the caller waits on them before it
     reuses the buffers it passed.  On the root, received(r) is what peer r >= 1
     sent in the most recently STARTED gather, once its handles have been waited
-    on; the root keeps two sets of receive buffers and alternates between them
-    like the caller does with its outputs, so that with two gathers in flight
-    the older one's data is not overwritten by the newer one's arrival
-    (received(r, slot) names a set: the k-th start() fills set k & 1).
+    on; the root keeps `slots` sets of receive buffers (default two) and cycles
+    through them like the caller does with its outputs, so that with that many
+    gathers in flight an older one's data is not overwritten by a newer one's
+    arrival (received(r, slot) names a set: the k-th start() fills set k % slots).
 
     cols: how many columns of the [nstreams, frames_cap] byte buffer can hold
     data at all (the caller knows its streams' lengths: mifsk_max_frames of the
     longest) -- only those are shipped, from a narrow staging copy made on the
-    caller's stream (two of them, used alternately like the caller's buffers).
+    caller's stream (`slots` of them, used in turn like the caller's buffers).
     rows: streams per rank when the shards differ in size (default: all ranks
     hold as many as this one)."""
 
-    def __init__(self, dist, rank, world, cols=None, rows=None):
+    def __init__(self, dist, rank, world, cols=None, rows=None, slots=2):
         self.dist, self.rank, self.world = dist, rank, world
         self.cols, self.rows = cols, rows
-        self._rx = [None, None]
-        self._tx = [None, None]
+        self.slots = max(2, int(slots))
+        self._rx = [None] * self.slots
+        self._tx = [None] * self.slots
         self._k = 0
         self._last = 0
 
@@ -407,7 +408,7 @@ class ByteGatherer:
         cols = local_bytes.shape[1] if self.cols is None else min(int(self.cols), local_bytes.shape[1])
         self.cols = cols
         if self.rank == 0:
-            slot = self._k & 1
+            slot = self._k % self.slots
             self._k += 1
             self._last = slot
             if self._rx[slot] is None:
@@ -424,7 +425,7 @@ class ByteGatherer:
         else:
             tx = local_bytes
             if cols != local_bytes.shape[1]:
-                b = self._k & 1
+                b = self._k % self.slots
                 self._k += 1
                 if self._tx[b] is None:
                     self._tx[b] = _torch().empty((local_bytes.shape[0], cols), dtype=local_bytes.dtype,
@@ -435,7 +436,7 @@ class ByteGatherer:
         return dist.batch_isend_irecv(ops)
 
     def received(self, r, slot=None):
-        return self._rx[self._last if slot is None else slot & 1][r - 1]
+        return self._rx[self._last if slot is None else slot % self.slots][r - 1]
 
 
 DECODERS = {"ascii8": 0, "baudot": 1, "binary": 2, "callerid": 3, "uic-ground": 4, "uic-train": 5}

@@ -218,12 +218,13 @@ def test_bench_spawns_its_own_ranks_when_no_launcher_is_around():
     assert d["dry_run"] and d["n_gpus"] == 2 and d["total_streams"] == 2048
 
 
-def _world8_worker(rank, world, port, q):
+def _world8_worker(rank, world, port, q, depth=2):
     """bench.py's timed loop at the size of the node it is written for: EIGHT ranks, unequal
-    shards (1027 streams: 129 129 129 128 ...), the narrow gather (`cols`), double-buffered
-    outputs with the gather of step i overlapped with step i + 1, the root fanning in from
-    seven peers at once -- and one rank that fails in the middle of the loop, which must end
-    in RankFailed on every rank (agree()) after every gather has still been joined."""
+    shards (1027 streams: 129 129 129 128 ...), the narrow gather (`cols`), `depth` output sets
+    with the gather of step i overlapped with the steps after it (bench.py --pipeline: passes in
+    flight), the root fanning in from seven peers at once -- and one rank that fails in the
+    middle of the loop, which must end in RankFailed on every rank (agree()) after every
+    gather has still been joined."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -235,10 +236,10 @@ def _world8_worker(rank, world, port, q):
         spans = [M.shard_range(total, r, world) for r in range(world)]
         rows = [b - a for a, b in spans]
         lo, hi = spans[rank]
-        g = M.ByteGatherer(dist, rank, world, cols=cols, rows=rows)
+        g = M.ByteGatherer(dist, rank, world, cols=cols, rows=rows, slots=depth)
         bufs = [(torch.zeros((rows[rank], cap), dtype=torch.uint8), torch.zeros(rows[rank], dtype=torch.int32))
-                for _ in range(2)]
-        pending = [None, None]
+                for _ in range(depth)]
+        pending = [None] * depth
         failure = None
         checked = 0
 
@@ -259,21 +260,21 @@ def _world8_worker(rank, world, port, q):
                 gid = torch.arange(plo, phi, dtype=torch.int64).reshape(-1, 1)
                 j = torch.arange(cols, dtype=torch.int64).reshape(1, -1)
                 # (rank 5's launch of step 3 failed: it still joined the gather, with what its
-                # buffer held -- step 1's bytes)
-                es = step - 2 if (r == 5 and step == 3) else step
+                # buffer held -- the bytes of the step that last wrote that set)
+                es = step - depth if (r == 5 and step == 3) else step
                 assert torch.equal(rb, ((gid + 3 * j + es) % 251).to(torch.uint8)), (r, step)
                 assert torch.equal(rn, ((torch.arange(plo, phi) + es) % (cols + 1)).to(torch.int32)), (r, step)
                 n += phi - plo
             return n
 
         for step in range(steps):
-            b = step & 1
+            b = step % depth
             if pending[b] is not None:
                 for w in pending[b]:
                     w.wait()
                 pending[b] = None
                 if rank == 0:
-                    checked += check(step - 2)
+                    checked += check(step - depth)
             try:
                 if rank == 5 and step == 3:
                     raise RuntimeError("launch failed on rank 5")
@@ -281,7 +282,7 @@ def _world8_worker(rank, world, port, q):
             except Exception as e:				# noqa: BLE001 -- this rank still joins every gather
                 failure = failure or e
             pending[b] = g.start(*bufs[b])
-        for b in ((steps) & 1, (steps + 1) & 1):		# oldest first
+        for b in [(steps + k) % depth for k in range(depth)]:	# oldest first
             if pending[b] is not None:
                 for w in pending[b]:
                     w.wait()
@@ -297,12 +298,13 @@ def _world8_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_eight_ranks_pipelined_narrow_gather_unequal_shards_one_failing_rank():
+@pytest.mark.parametrize("depth", [2, 3])
+def test_eight_ranks_pipelined_narrow_gather_unequal_shards_one_failing_rank(depth):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     world = 8
-    procs = [ctx.Process(target=_world8_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_world8_worker, args=(r, world, port, q, depth)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}
@@ -314,8 +316,9 @@ def test_eight_ranks_pipelined_narrow_gather_unequal_shards_one_failing_rank():
         assert p.exitcode == 0
     rows = got[0][0]
     assert rows == [129, 129, 129, 128, 128, 128, 128, 128] and sum(rows) == 1027
-    # the root verified every peer's rows of four completed gathers (steps 0..3) inside the loop
-    assert got[0][1] == 4 * (1027 - 129)
+    # the root verified every peer's rows of the gathers completed inside the loop (six steps:
+    # steps 0..3 with two output sets, 0..2 with three)
+    assert got[0][1] == (6 - depth) * (1027 - 129)
     for r in range(world):
         assert got[r][2] == ("failed:mine" if r == 5 else "failed:peer"), (r, got[r][2])
         assert got[r][3] == rows[r] * 9 + 4 * rows[r]

@@ -86,8 +86,10 @@ def main():
         src = os.path.join(ROOT, "gpurun_out", "profile_%s_%s" % (tag, c))
         pre = "%s_%s" % (tag, c)
         for a, b in (("bench.json", "bench.json"), ("stats_kernel_stats.csv", "kernel_stats.csv"),
-                     ("bench_under_rocprof.log", "bench_under_rocprof.log")):
-            shutil.copy(os.path.join(src, a), os.path.join(dst, "%s_%s" % (pre, b)))
+                     ("bench_under_rocprof.log", "bench_under_rocprof.log"),
+                     ("statspipe_kernel_stats.csv", "kernel_stats_pipelined.csv")):
+            if os.path.exists(os.path.join(src, a)) or not a.startswith("statspipe"):
+                shutil.copy(os.path.join(src, a), os.path.join(dst, "%s_%s" % (pre, b)))
         b = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
         alg = b["roofline"]["algorithmic_bytes_per_launch"]
         # chained launches: one pass over the batch is groups x chunks dispatches
@@ -140,6 +142,13 @@ def main():
                           % (c, r["Name"][:48], r["Calls"], float(r["AverageNs"]) / 1e3, b["roofline"]["kernel_ms_avg"] * 1e3,
                              "; a pass is %d x %d dispatches, the %d groups' overlapping: average x %d = %.1f us"
                              % (groups, chunks, groups, chunks, float(r["AverageNs"]) / 1e3 * chunks) if groups else ""))
+        if os.path.exists(os.path.join(src, "statspipe_kernel_stats.csv")):
+            with open(os.path.join(src, "statspipe_kernel_stats.csv")) as f:
+                for r in csv.DictReader(f):
+                    if is_demod(r["Name"]):
+                        print("%s: the default command (%s passes in flight): %s calls, average %.1f us each; %.1f us per pass"
+                              % (c, (b.get("pipeline") or {}).get("passes_in_flight"), r["Calls"],
+                                 float(r["AverageNs"]) / 1e3, b["ms_per_step"] * 1e3))
         print("%s: HBM bytes/launch %.3e = %.2f x algorithmic; VALU wave-insts/launch %.3e; frac %.3f"
               % (c, hbm, hbm / alg, sq["SQ_INSTS_VALU"], b["roofline"]["frac"]))
 
