@@ -319,9 +319,13 @@ def run_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, cp
             _LANES[pipe] = ([ctx] + [M.Context(torch.cuda.current_device()) for _ in range(pipe - 1)],
                             [None] if pipe == 1 else [torch.cuda.Stream() for _ in range(pipe)])
         ctxs, streams = _LANES[pipe]
-        bufs = [M.demod_batch(ctxs[k % pipe], cfg, samples, stream=streams[k % pipe], **kw)
+        # every lane reads a copy of the batch of its own: three batches in flight, not three
+        # readers of one (no pass can find another's samples in a cache)
+        copies = [samples] + [samples.clone() for _ in range(pipe - 1)]
+        torch.cuda.synchronize()
+        bufs = [M.demod_batch(ctxs[k % pipe], cfg, copies[k % pipe], stream=streams[k % pipe], **kw)
                 for k in range(max(2, pipe))]
-        lanes = (ctxs, streams)
+        lanes = (ctxs, streams, copies)
         torch.cuda.synchronize()
     except Exception as e:				# noqa: BLE001
         setup_err = e
@@ -424,7 +428,7 @@ def work_counters(name, M, torch, ctx, cfg, samples, lens, kw):
 def timed_workload(name, args, M, torch, dist, ctx, lanes, rank, world, steps, warmup, cpu_leg, oracle_leg,
                    cfg, mode, entry, samples, lens, bufs, kw, payloads, lo, nstreams, nsamp, stride,
                    frames_cap, total_streams, total_samples_local):
-    ctxs, streams = lanes
+    ctxs, streams, copies = lanes
     pipe = len(ctxs)
     nbuf = len(bufs)				# = max(2, pipe): pass i writes set i mod nbuf
     pending = [None] * nbuf
@@ -456,7 +460,7 @@ def timed_workload(name, args, M, torch, dist, ctx, lanes, rank, world, steps, w
             if events is not None:
                 events[0].record()
             try:
-                M.demod_batch(ctxs[lane], cfg, samples, stream=streams[lane], out=bufs[b], **kw)
+                M.demod_batch(ctxs[lane], cfg, copies[lane], stream=streams[lane], out=bufs[b], **kw)
             except Exception as e:		# noqa: BLE001 -- this rank still joins every gather
                 failure[0] = failure[0] or e
             if events is not None:
@@ -539,6 +543,7 @@ def timed_workload(name, args, M, torch, dist, ctx, lanes, rank, world, steps, w
     # (this rank's own clock stopped after the closing barrier: the same for all; what differs
     # per rank is how long its launches and its waits for the gather took)
     agree(torch, dist, failure[0], "%s: timed loop" % name)
+    del copies[1:]				# (the lanes' copies of the batch: nothing below reads them)
 
     kernel_ms = [a.elapsed_time(b) for a, b in evs]
     if region:
@@ -673,7 +678,7 @@ def timed_workload(name, args, M, torch, dist, ctx, lanes, rank, world, steps, w
             "pipeline": {"passes_in_flight": pipe, "streams": pipe,
                          "ms_per_pass": dt / steps * 1e3,
                          "hbm_frac_of_the_timed_passes": total_samples_local * 4.0 * steps / dt / HBM_PEAK,
-                         "note": "pass i runs on stream i mod P (own context, own outputs): it fills the CUs "
+                         "note": "pass i runs on stream i mod P (own context, own copy of the batch, own outputs): it fills the CUs "
                                  "the late streams of pass i - 1 leave idle; roofline.* is the kernel launched "
                                  "serially on one stream"},
             "preheat": {"untimed_launches_before_warmup": preheat["launches"], "ms": preheat["ms"],
