@@ -48,6 +48,12 @@ from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
+# Passes in flight need hardware queues of their own: HIP multiplexes a process's streams onto
+# GPU_MAX_HW_QUEUES hardware queues (4 by default -- the null stream and three lanes), and lanes
+# that share one run one after the other.  Read when the HIP runtime starts, i.e. before torch is
+# imported (in main()); a value the caller has set is kept.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -269,7 +275,7 @@ def agree(torch, dist, err, what):
         raise RankFailed("%s: %s" % (what, repr(err) if err is not None else "another rank failed"))
 
 
-_LANES = {}
+_LANES = []
 
 
 def run_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, cpu_leg, oracle_leg=True):
@@ -310,15 +316,19 @@ def run_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, cp
     # context owns its launch scratch) and its own output set, so that pass i + 1 fills the CUs
     # that pass i's late streams leave idle (a launch ends ~20 % after its mean stream on
     # configs[1], and long after it under impairments: DESIGN.md section 6).
-    pipe = max(1, int(args.pipeline))
+    # (0 = this workload's own depth: three where the launch is one kernel whose tail is short
+    # against its body -- K = 20, each lane on its own copy of the batch: 2, 3, 4, 5 in flight
+    # give 0.351, 0.351, 0.355, 0.357 ms per pass on configs[1] -- four where the launches are
+    # long serial chains or chained dispatches: 1200noise 0.90 -> 0.77, SAME 7.7 -> 7.3 ms)
+    pipe = int(args.pipeline) if args.pipeline > 0 else {"1200": 3, "12000": 3}.get(name, 4)
     lanes = None
     try:
         # (made once per process and shared by the workloads: HIP multiplexes streams onto a few
         # hardware queues, and lanes created anew for every workload end up sharing one)
-        if pipe not in _LANES:
-            _LANES[pipe] = ([ctx] + [M.Context(torch.cuda.current_device()) for _ in range(pipe - 1)],
-                            [None] if pipe == 1 else [torch.cuda.Stream() for _ in range(pipe)])
-        ctxs, streams = _LANES[pipe]
+        while len(_LANES) < pipe:
+            _LANES.append((ctx if not _LANES else M.Context(torch.cuda.current_device()), torch.cuda.Stream()))
+        ctxs = [c for c, _ in _LANES[:pipe]]
+        streams = [None] if pipe == 1 else [s for _, s in _LANES[:pipe]]
         # every lane reads a copy of the batch of its own: three batches in flight, not three
         # readers of one (no pass can find another's samples in a cache)
         copies = [samples] + [samples.clone() for _ in range(pipe - 1)]
@@ -676,6 +686,7 @@ def timed_workload(name, args, M, torch, dist, ctx, lanes, rank, world, steps, w
             "payload_roundtrip_ok_streams": "%d/%d" % (ok_streams, judged),
             "device": ctx.device_name,
             "pipeline": {"passes_in_flight": pipe, "streams": pipe,
+                         "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
                          "ms_per_pass": dt / steps * 1e3,
                          "hbm_frac_of_the_timed_passes": total_samples_local * 4.0 * steps / dt / HBM_PEAK,
                          "note": "pass i runs on stream i mod P (own context, own copy of the batch, own outputs): it fills the CUs "
@@ -829,8 +840,9 @@ def main():
                     help="skip the CPU legs (the timed baselines and the whole-batch oracle verdict)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the H2D-inclusive leg")
     ap.add_argument("--no-extra", action="store_true", help="configs[1] only: skip configs[2..4]")
-    ap.add_argument("--pipeline", type=int, default=3,
-                    help="passes in flight: pass i is launched on stream i mod P (1 = one stream)")
+    ap.add_argument("--pipeline", type=int, default=0,
+                    help="passes in flight: pass i is launched on stream i mod P (1 = one stream; "
+                         "0 = the workload's own default, 3 or 4)")
     ap.add_argument("--preheat-ms", type=float, default=300.0,
                     help="untimed kernel launches before the W warm-up passes (0 = none)")
     ap.add_argument("--step-events", action="store_true",

@@ -7,6 +7,7 @@ used by the tests, the benchmark and Python callers: it marshals arguments,
 uses PyTorch only for device memory / streams / torch.distributed, and raises
 if the native library is missing -- there is no fallback implementation.
 """
+import contextlib
 import ctypes as C
 import os
 import subprocess
@@ -104,6 +105,12 @@ def _torch():
     return torch
 
 
+def _on(torch, stream):
+    """Allocations and fills that a launch on `stream` depends on are queued ON that stream
+    (torch orders a fill on its current stream only: on another one it would race the kernel)."""
+    return torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
+
+
 def _stream_ptr(torch, stream):
     if stream is None:
         stream = torch.cuda.current_stream()
@@ -154,25 +161,28 @@ def demod_batch(ctx, cfg, samples, nsamples=None, want=("bytes", "episodes"),
         frames_cap = max_frames(cfg, n_uniform)
     dev = samples.device
     if out is None:
-        out = {}
-        out["nframes"] = torch.zeros(nstreams, dtype=torch.int32, device=dev)
-        out["status"] = torch.zeros(nstreams, dtype=torch.int32, device=dev)
-        if "bytes" in want:
-            out["bytes"] = torch.zeros((nstreams, frames_cap), dtype=torch.uint8, device=dev)
-            out["nbytes"] = torch.zeros(nstreams, dtype=torch.int32, device=dev)
-        if "bits" in want:
-            out["bits"] = torch.zeros((nstreams, frames_cap), dtype=torch.int64, device=dev)
-        if "frames" in want:
-            out["frames"] = torch.zeros((nstreams, frames_cap, FRAME_DTYPE.itemsize),
-                                        dtype=torch.uint8, device=dev)
-        if "counters" in want:
-            out["counters"] = torch.zeros((nstreams, NCOUNTERS), dtype=torch.int64, device=dev)
-        if "carrier_band" in want or cfg.auto_carrier_threshold > 0:
-            out["carrier_band"] = torch.full((nstreams,), -1, dtype=torch.int32, device=dev)
-        if "episodes" in want:
-            out["episodes"] = torch.zeros((nstreams, episodes_cap, EPISODE_DTYPE.itemsize),
-                                          dtype=torch.uint8, device=dev)
-            out["nepisodes"] = torch.zeros(nstreams, dtype=torch.int32, device=dev)
+        # (allocated and zero-filled ON the launch stream: a fill queued on torch's current
+        # stream would race a kernel launched on another one)
+        with _on(torch, stream):
+            out = {}
+            out["nframes"] = torch.zeros(nstreams, dtype=torch.int32, device=dev)
+            out["status"] = torch.zeros(nstreams, dtype=torch.int32, device=dev)
+            if "bytes" in want:
+                out["bytes"] = torch.zeros((nstreams, frames_cap), dtype=torch.uint8, device=dev)
+                out["nbytes"] = torch.zeros(nstreams, dtype=torch.int32, device=dev)
+            if "bits" in want:
+                out["bits"] = torch.zeros((nstreams, frames_cap), dtype=torch.int64, device=dev)
+            if "frames" in want:
+                out["frames"] = torch.zeros((nstreams, frames_cap, FRAME_DTYPE.itemsize),
+                                            dtype=torch.uint8, device=dev)
+            if "counters" in want:
+                out["counters"] = torch.zeros((nstreams, NCOUNTERS), dtype=torch.int64, device=dev)
+            if "carrier_band" in want or cfg.auto_carrier_threshold > 0:
+                out["carrier_band"] = torch.full((nstreams,), -1, dtype=torch.int32, device=dev)
+            if "episodes" in want:
+                out["episodes"] = torch.zeros((nstreams, episodes_cap, EPISODE_DTYPE.itemsize),
+                                              dtype=torch.uint8, device=dev)
+                out["nepisodes"] = torch.zeros(nstreams, dtype=torch.int32, device=dev)
 
     def ptr(name):
         t = out.get(name)
@@ -249,8 +259,9 @@ def find_frame_batch(ctx, cfg, samples, problems, stream=None):
     assert samples.is_cuda and samples.dtype == torch.float32
     problems = np.ascontiguousarray(problems, dtype=SEARCH_DTYPE)
     n = problems.shape[0]
-    d_prob = torch.from_numpy(problems.view(np.uint8).reshape(-1).copy()).to(samples.device)
-    d_res = torch.zeros(n * RESULT_DTYPE.itemsize, dtype=torch.uint8, device=samples.device)
+    with _on(torch, stream):
+        d_prob = torch.from_numpy(problems.view(np.uint8).reshape(-1).copy()).to(samples.device)
+        d_res = torch.zeros(n * RESULT_DTYPE.itemsize, dtype=torch.uint8, device=samples.device)
     rc = lib.mifsk_find_frame_batch(ctx.handle, C.byref(cfg), C.c_void_p(samples.data_ptr()),
                                     C.c_void_p(d_prob.data_ptr()), C.c_void_p(d_res.data_ptr()),
                                     n, _stream_ptr(torch, stream))
@@ -561,8 +572,9 @@ def synthesize_batch(ctx, cfg, words, nwords=None, lut=4096, amplitude=1.0, lead
         n = _lib.load().mifsk_tx_synthesize(C.byref(cfg), one.ctypes.data, max_words, lut,
                                             C.c_float(amplitude), max_lead, 0, None, 0)
         stride = (max(int(n), 4) + 3) & ~3
-    out = torch.empty((nstreams, stride), dtype=torch.float32, device=words.device)
-    lens = torch.zeros(nstreams, dtype=torch.int32, device=words.device)
+    with _on(_torch(), stream):
+        out = torch.empty((nstreams, stride), dtype=torch.float32, device=words.device)
+        lens = torch.zeros(nstreams, dtype=torch.int32, device=words.device)
     rc = _lib.load().mifsk_tx_synthesize_batch(
         ctx.handle, C.byref(cfg), C.c_void_p(words.data_ptr()),
         words.stride(0) if nstreams > 1 else width,
@@ -786,21 +798,22 @@ class SlabSession:
         for i, t in enumerate(self.tail):
             host[i, :len(t)] = t
             lens[i] = len(t)
-        d = torch.from_numpy(host).cuda()
-        dl = torch.from_numpy(lens).cuda()
-        do = torch.from_numpy(self.origin.view(np.int64).copy()).cuda()
-        fc = max_frames(self.cfg, width)
-        dev = d.device
-        out = {"nframes": torch.zeros(self.n, dtype=torch.int32, device=dev),
-               "status": torch.zeros(self.n, dtype=torch.int32, device=dev),
-               "bytes": torch.zeros((self.n, fc), dtype=torch.uint8, device=dev),
-               "nbytes": torch.zeros(self.n, dtype=torch.int32, device=dev),
-               "bits": torch.zeros((self.n, fc), dtype=torch.int64, device=dev),
-               "frames": torch.zeros((self.n, fc, FRAME_DTYPE.itemsize), dtype=torch.uint8, device=dev),
-               "episodes": torch.zeros((self.n, self.episodes_cap, EPISODE_DTYPE.itemsize),
-                                       dtype=torch.uint8, device=dev),
-               "nepisodes": torch.zeros(self.n, dtype=torch.int32, device=dev),
-               "carrier_band": torch.full((self.n,), -1, dtype=torch.int32, device=dev)}
+        with _on(torch, stream):
+            d = torch.from_numpy(host).cuda()
+            dl = torch.from_numpy(lens).cuda()
+            do = torch.from_numpy(self.origin.view(np.int64).copy()).cuda()
+            fc = max_frames(self.cfg, width)
+            dev = d.device
+            out = {"nframes": torch.zeros(self.n, dtype=torch.int32, device=dev),
+                   "status": torch.zeros(self.n, dtype=torch.int32, device=dev),
+                   "bytes": torch.zeros((self.n, fc), dtype=torch.uint8, device=dev),
+                   "nbytes": torch.zeros(self.n, dtype=torch.int32, device=dev),
+                   "bits": torch.zeros((self.n, fc), dtype=torch.int64, device=dev),
+                   "frames": torch.zeros((self.n, fc, FRAME_DTYPE.itemsize), dtype=torch.uint8, device=dev),
+                   "episodes": torch.zeros((self.n, self.episodes_cap, EPISODE_DTYPE.itemsize),
+                                           dtype=torch.uint8, device=dev),
+                   "nepisodes": torch.zeros(self.n, dtype=torch.int32, device=dev),
+                   "carrier_band": torch.full((self.n,), -1, dtype=torch.int32, device=dev)}
         io = _lib.DemodIO()
         io.d_samples = d.data_ptr()
         io.stream_stride = d.stride(0) if self.n > 1 else width

@@ -16,7 +16,7 @@ for C in $CONFIGS; do
   #    is (bench.py takes it from K serial launches right after the timed passes) ...
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o stats -- \
       $B --steps 20 --warmup 3 --pipeline 1 > $OUT/bench_under_rocprof.log 2>&1
-  #    ... and the very command the bench line comes from (three passes in flight: the timed
+  #    ... and the very command the bench line comes from (three or four passes in flight: the timed
   #    launches overlap, so each one's own duration is longer while the passes per second go up)
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o statspipe -- \
       $B --steps 20 --warmup 3 > $OUT/bench_under_rocprof_pipelined.log 2>&1
