@@ -200,9 +200,7 @@ __device__ __forceinline__ void lds_poke( uint32_t *p, uint32_t v ) { *(lds_vu32
 template <typename T>
 __device__ __forceinline__ T keep_scalar( T v )
 {
-#ifndef MIFSK_X_NOHOIST
     asm volatile("" : "+s"(v));
-#endif
     return v;
 }
 
@@ -586,15 +584,11 @@ struct Master {
 	// what the candidates read
 	const uint32_t lo = base + first - zz.D * zz.step + cfg.bit_offset[0];
 	const uint32_t hi = base + first + ( zz.U - 1u ) * zz.step + cfg.bit_offset[( nb - 1u ) & 63u] + B;
-#ifndef MIFSK_X_NOSOLO2
 	// The span is staged from `lo` itself (the 16-byte global loads need no alignment): with an
 	// even search step every window then starts an EVEN number of samples into the buffer (bit
 	// offsets are multiples of 4 here) and is read two samples per LDS instruction.
 	const uint32_t org4 = lo;
 	const bool pairs = ( zz.step & 1u ) == 0u;
-#else
-	const uint32_t org4 = lo & ~3u;
-#endif
 	const uint32_t nvec = ( hi - org4 + 3u ) >> 2;
 	if ( hi > N || hi < lo || org4 + 4u * nvec > N || nvec > 128u
 		|| nvec * 16u + nwin * sizeof(float2) > sizeof(lds->mags[0]) )
@@ -617,7 +611,6 @@ struct Master {
 	asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #endif
 	const uint32_t t_sf1 = MIFSK_CLOCK();
-#ifndef MIFSK_X_NOSOLO2
 	{
 	    // ONE pass: lane l sums window l AND window l + 64 (slots without a window shadow a real
 	    // one: every lane must be active for the broadcasts) -- eight independent accumulator
@@ -671,35 +664,6 @@ struct Master {
 		sm[lane + 64u] = make_float2(band_mag(accB[0], accB[1], cfg.magscalar),
 					     band_mag(accB[2], accB[3], cfg.magscalar));
 	}
-#else
-	for ( uint32_t w0 = 0; w0 < nwin; w0 += 64u ) {
-	    const uint32_t w = w0 + lane;
-	    const bool active = w < nwin;
-	    const uint32_t q = active ? udiv_magic(w, nb, cfg.nbits_magic) : 0u;
-	    const uint32_t k = active ? w - q * nb : 0u;
-	    const float *p = sbuf + ( base + zz.at(1u + q) + cfg.bit_offset[k & 63u] - org4 );
-	    float4 xs[NQ];
-#pragma unroll
-	    for ( int i = 0; i < NQ; i++ )
-		xs[i] = make_float4(p[4 * i], p[4 * i + 1], p[4 * i + 2], p[4 * i + 3]);
-	    double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
-	    dpp_settle();
-#define MIFSK_SOLO_QUAD(Q)								\
-	    if ( (Q) < NQ ) {								\
-		if ( (Q) % 4 == 0 ) quad_bcast<0>(acc, tg[(Q) / 4], xs[(Q) < NQ ? (Q) : 0]);	\
-		if ( (Q) % 4 == 1 ) quad_bcast<4>(acc, tg[(Q) / 4], xs[(Q) < NQ ? (Q) : 0]);	\
-		if ( (Q) % 4 == 2 ) quad_bcast<8>(acc, tg[(Q) / 4], xs[(Q) < NQ ? (Q) : 0]);	\
-		if ( (Q) % 4 == 3 ) quad_bcast<12>(acc, tg[(Q) / 4], xs[(Q) < NQ ? (Q) : 0]);	\
-	    }
-	    MIFSK_SOLO_QUAD(0) MIFSK_SOLO_QUAD(1) MIFSK_SOLO_QUAD(2) MIFSK_SOLO_QUAD(3)
-	    MIFSK_SOLO_QUAD(4) MIFSK_SOLO_QUAD(5) MIFSK_SOLO_QUAD(6) MIFSK_SOLO_QUAD(7)
-	    MIFSK_SOLO_QUAD(8) MIFSK_SOLO_QUAD(9) MIFSK_SOLO_QUAD(10) MIFSK_SOLO_QUAD(11)
-#undef MIFSK_SOLO_QUAD
-	    if ( active )
-		sm[w] = make_float2(band_mag(acc[0], acc[1], cfg.magscalar),
-				    band_mag(acc[2], acc[3], cfg.magscalar));
-	}
-#endif
 	wave_lds_sync();
 	const uint32_t t_sf2 = MIFSK_CLOCK();
 	FrameOut f;
