@@ -3,7 +3,9 @@ contexts, six streams, the same batch launched on all of them back to back -- wi
 tensors allocated by the call itself -- must each give what a lone launch gives.  (Round 5: the
 wrapper zero-filled its outputs on torch's CURRENT stream while the kernel ran on the stream it was
 given; with the launches truly concurrent -- eight hardware queues -- a fill landed on a kernel's
-results.)  In a subprocess: GPU_MAX_HW_QUEUES is read when HIP starts."""
+results.)  With the fills put back on the current stream the script below fails under both
+queue settings (tools/gpu/racecheck.py: ('rtty', 1, 1, 'nframes'), ('1200', 2, 5, 'nbytes')).
+In a subprocess: GPU_MAX_HW_QUEUES is read when HIP starts."""
 import os
 import subprocess
 import sys
