@@ -26,9 +26,19 @@ the next step).  Streams shard across ranks with no data-path collective.
 the job's total fixed (8 x the per-GPU batch: 65536 streams for --config 12000,
 the size BASELINE.json states) and divides it over the ranks.
 
+Timing: before the W warm-up passes the kernel is launched untimed for
+0.3 s (`--preheat-ms`: the first launches after host-side set-up run at idle clocks, and the
+driver's K = 20 is 7-11 ms of GPU work); the K timed passes keep three or four passes in flight
+(`--pipeline`: pass i on HIP stream i mod P with its own context, its own copy of the batch and
+its own outputs, so that it fills the CUs the late streams of pass i - 1 leave idle), bracketed
+by barrier + synchronize as the contract says; `roofline` is the kernel launched SERIALLY on one
+stream (K launches between the preheat and the warm-up passes, one event pair around them).
+
 Prints ONE JSON line on rank 0 (contract in the task description), including
   roofline     : HBM-read roofline of the demod kernel, measured live with
-                 events on the launch stream
+                 events on the launch stream (serial launches, see above)
+  pipeline     : passes in flight, ms per pass and fraction of 8 TB/s of the timed passes
+  preheat      : the untimed launches before the warm-up
   cpu_baseline : the reference's own CPU path (oracle/_ref: unmodified
                  src/*.c + FFT shim), one process per host core, on a bounded
                  sample of the same batch
