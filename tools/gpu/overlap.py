@@ -13,6 +13,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="1200")
 ap.add_argument("--steps", type=int, default=40)
 ap.add_argument("--pipes", default="1,2,3,4")
+ap.add_argument("--copies", default="shared", choices=["shared", "separate", "contiguous"],
+                help="what the lanes read: one batch, a clone each, or slices of one big allocation")
 args = ap.parse_args()
 ctx0 = M.Context(0)
 P = max(int(p) for p in args.pipes.split(","))
@@ -29,9 +31,18 @@ for name in args.config.split(","):
   torch.cuda.synchronize()		# (the batch is made on torch's current stream)
   frames_cap = M.max_frames(cfg, stride)
   kw = dict(want=("bytes",), frames_cap=frames_cap, nsamples=lens, episodes_cap=8)
+  if args.copies == "separate":
+      src = [samples] + [samples.clone() for _ in range(P - 1)]
+  elif args.copies == "contiguous":
+      big = torch.empty((P,) + tuple(samples.shape), dtype=samples.dtype, device=samples.device)
+      big[:] = samples
+      src = [big[k] for k in range(P)]
+  else:
+      src = [samples] * P
+  torch.cuda.synchronize()
   bufs = []
-  for c, st in zip(ctxs, streams):
-      bufs.append(M.demod_batch(c, cfg, samples, stream=st, **kw))
+  for c, st, x in zip(ctxs, streams, src):
+      bufs.append(M.demod_batch(c, cfg, x, stream=st, **kw))
   torch.cuda.synchronize()
   ref = M.results_to_host(bufs[0])
   for b in bufs[1:]:
@@ -49,7 +60,7 @@ for name in args.config.split(","):
           t0 = time.perf_counter()
           for i in range(args.steps):
               k = i % p
-              M.demod_batch(ctxs[k], cfg, samples, stream=streams[k], out=bufs[k], **kw)
+              M.demod_batch(ctxs[k], cfg, src[k], stream=streams[k], out=bufs[k], **kw)
           torch.cuda.synchronize()
           ts.append((time.perf_counter() - t0) / args.steps * 1e3)
       med = float(np.median(ts))
