@@ -7,9 +7,15 @@
 namespace mifsk {
 
 // |X[b]| * scalar, as the reference computes it (fsk.c:107-114): the FFT output
-// is a pair of floats; hypotf in glibc 2.35 is exactly
-// (float)sqrt((double)re*re + (double)im*im) (verified exhaustively on the
-// host, tests/test_host_math.py); f64 sqrt on gfx950 is correctly rounded.
+// is a pair of floats; hypotf in glibc 2.35 is (float)sqrt((double)re*re +
+// (double)im*im) bit for bit -- pinned to the running C library by a sweep of
+// 2 x 2^24 pairs in the CPU suite (tests/test_host_math.py; tools/hypotf_check.c 29 compares
+// 10^9) -- with C's one special rule hypot(+-inf, NaN) = +inf, where this returns NaN.  That
+// pair arises only in a window whose FIRST sample is infinite (-sin 0 = -0.0, inf * -0.0 =
+// NaN) and then in both bands alike: the reference sees bit 0 with signal = noise = inf and
+// its confidence sum is inf / inf, here it is NaN / x -- a NaN confidence either way, which
+// never wins a search (fsk.c:492; tests/test_gpu_parity.py: non-finite samples, runs of
+// infinities three bit windows long included).  f64 sqrt on gfx950 is correctly rounded.
 // sqrt() of a double that is 0 or at least 2^-298 (a sum of squares of floats):
 // the compiler's own correctly rounded sequence for gfx950 -- v_rsq_f64, one
 // coupled Newton step on (g ~ sqrt s, h ~ 1/(2 sqrt s)), two residual

@@ -972,6 +972,12 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
     for (;;) {
 	if ( ST && !resumable )
 	    break;
+	// A lattice frame that failed the replay below and goes through the general path: its
+	// coarse search is known -- the first try is that scored frame, and a first try at or above
+	// the limit ends the search (fsk.c:492,499) -- so the iteration is entered behind it.
+	bool fwd = false;
+	ScanResult fwd_sr;
+	fwd_sr.conf = 0.0f; fwd_sr.ampl = 0.0f; fwd_sr.bits = 0; fwd_sr.start = 0;
 	// ------------------------------------------------------------------
 	// Bulk acceptance of lattice frames.  While carrier is held and the
 	// cursor lands on the lattice, the reference's iteration for frame k
@@ -987,7 +993,7 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 	    const uint32_t nb = base + advance;		// cursor of the next iteration
 	    const uint32_t p = nb + first;
 	    const uint32_t e0 = ctx.lattice_lookup(p);
-	    bool progressed = false;
+	    bool progressed = false, broke = false;
 	    if ( e0 != ~0u ) {
 		uint32_t K = ctx.lat_n - e0;
 		// frame k sits at cursor nb + k*lock_advance and needs expect_nsamples from there
@@ -1122,13 +1128,27 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 		    ctx.bump(MIFSK_CNT_BULK_FRAMES, n);
 		    progressed = true;
 		}
+		if ( n < K ) {
+		    // Frame n is the next iteration's, and it is not a trivial one: straight to the
+		    // general path (a second replay would only find n = 0 again), with the coarse
+		    // search's answer where the first try decides it.
+		    broke = true;
+		    const float cn = lane_bcast(cv, n);
+		    if ( cn > 0.0f && cn >= h_limit ) {
+			fwd = true;
+			fwd_sr.conf = cn;
+			fwd_sr.ampl = lane_bcast(av, n);
+			fwd_sr.bits = lds->c_bits[e0 + n];
+			fwd_sr.start = first;
+		    }
+		}
 	    } else if ( ctx.inflight && ctx.inflight_anchor == p ) {
 		// the cursor has walked onto the batch the workers are finishing
 		ctx.lattice_advance();
 		progressed = true;
 	    }
 	    cyc_bulk += MIFSK_CLOCK() - t_bulk;
-	    if ( progressed )
+	    if ( progressed && !broke )
 		continue;
 	}
 
@@ -1178,8 +1198,14 @@ __device__ __forceinline__ void master_loop( const DevCfg &cfg, const double *__
 	const uint32_t try_first = carrier ? h_first1 : h_first0;
 
 	const uint32_t t_s1 = MIFSK_CLOCK();
-	ScanResult sr =ctx.scan(base, carrier ? zc1 : zc0, try_first, h_limit,
-				 carrier ? 0u : 1u);		// minimodem.c:1265-1274
+	ScanResult sr;						// minimodem.c:1265-1274
+	if ( fwd ) {
+	    sr = fwd_sr;		// (what scan() returns for a scored first try at or above the limit)
+	    ctx.hit_base = base;
+	    ctx.bump(MIFSK_CNT_CACHE_HITS);
+	} else {
+	    sr = ctx.scan(base, carrier ? zc1 : zc0, try_first, h_limit, carrier ? 0u : 1u);
+	}
 	cyc_s1 += MIFSK_CLOCK() - t_s1;
 	float confidence = sr.conf;
 	float amplitude = sr.ampl;

@@ -1277,7 +1277,7 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 		ctx.lattice_block(p, F);
 		e0 = 0;
 	    }
-	    bool progressed = false;
+	    bool progressed = false, broke = false;
 	    if ( e0 != ~0u ) {
 		uint32_t K = ctx.lat_n - e0;
 		K = K < room ? K : room;
@@ -1321,6 +1321,9 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 		const unsigned long long bad = __ballot(have && !ok);
 		const uint32_t n = bad ? (uint32_t)__ffsll((long long)bad) - 1u : K;
 		ctx.run += n;
+		// (frame n is the next iteration's and not a trivial one: straight to the general
+		// path below -- a second replay would only find n = 0 again)
+		broke = n < K;
 		if ( n < K ) {			// the lattice broke here: remember how long it held
 		    ctx.spec = ctx.run < g.lat_fmin ? g.lat_fmin
 			     : ( ctx.run < g.lat_fmax ? ctx.run : g.lat_fmax );
@@ -1408,7 +1411,7 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 		}
 	    }
 	    cyc_bulk += MIFSK_WCLOCK() - t_bulk;	// (block evaluation included)
-	    if ( progressed )
+	    if ( progressed && !broke )
 		continue;
 	}
 	const uint32_t t_gen = MIFSK_WCLOCK();
