@@ -21,6 +21,7 @@
  *   mifsk_ctx_create/destroy      fsk_plan_new/destroy   fsk.c:33-104
  *   mifsk_find_frame_batch        fsk_find_frame         fsk.c:449-538 (N problems)
  *   mifsk_demod_batch             the --rx main loop     minimodem.c:1137-1463
+ *   mifsk_pipeline_*              ... several batches in flight (lanes of context + stream)
  *   mifsk_demod_batch_host[_ex]   same, host buffers     (chunked H2D | demod | D2H, overlapped)
  *   mifsk_demod_files             --rx --file, N files   simpleaudio-sndfile.c:42-74,
  *                                                        minimodem.c:1014-1032
@@ -36,7 +37,7 @@ extern "C" {
 #endif
 
 #define MIFSK_MAX_FRAME_BITS	64	/* fsk.c:185-187,463 */
-#define MIFSK_ABI_VERSION	7
+#define MIFSK_ABI_VERSION	8
 
 /* which databits decoder main() would have selected (minimodem.c:549-553,
  * 675,820,856,866,892).  Decoding frame bits to text is O(1)/frame host work
@@ -154,6 +155,15 @@ int  mifsk_abi_version( void );
  * for a name it does not know: lets a foreign-function binding check its mirror of the
  * layouts before it passes one across (tests/test_config.py does, for the ctypes mirror). */
 size_t mifsk_abi_sizeof( const char *name );
+
+/* Diagnostic: the kernels take (float)sqrt(fr^2 + fi^2) of a bit window's sums (the reference's
+ * hypotf, fsk.c:107-114) by a short sequence wherever that is provably the float the correctly
+ * rounded one gives, and by the exact sequence otherwise (csrc/mifsk_devmath.h).  This runs both
+ * on `nvalues` sums of squares (half of them placed at float rounding boundaries) and counts:
+ * [0] short results accepted as safe that differ from the exact ones -- must be 0, [1] values
+ * the guard sent to the exact sequence, [2] values whose unguarded short result differs,
+ * [3] values evaluated.  Synchronous. */
+int mifsk_selftest_sqrt( mifsk_ctx *ctx, uint64_t seed, uint64_t nvalues, uint64_t counts[4] );
 
 /* ---- N independent fsk_find_frame() problems --------------------------- */
 
@@ -291,9 +301,80 @@ typedef struct mifsk_demod_io {
  * mifsk_launch_info.chain_groups below; nothing changes for the caller.)  Calls on ONE
  * context are ordered by the caller (a context owns its launch scratch); to keep several
  * batches in flight -- a launch ends well after its mean stream, so the next one fills the
- * chip -- give each stream a context of its own (INTEGRATION.md 2a', bench.py --pipeline). */
+ * chip -- use a mifsk_pipeline (below), which gives each pass a context and a stream. */
 int mifsk_demod_batch( mifsk_ctx *ctx, const mifsk_rx_config *cfg,
 	const mifsk_demod_io *io, void *stream );
+
+/* ---- several batches in flight ---------------------------------------------- */
+
+/* A launch ends well after its mean stream (the streams of a batch are serial chains of unequal
+ * length), so the way to keep the chip full is to have the next batch running under the tail of
+ * this one.  A pipeline owns what that needs: `depth` lanes -- each a context, a HIP stream and a
+ * completion event of its own -- and, if asked, `depth` sets of output arrays.  Pass number t
+ * (its "ticket", counting from 0) runs on lane t % depth, behind whatever ran on that lane
+ * before.  For the reference's call site -- one file after another through the batch entry,
+ * src/minimodem.c:1265,1373 via integration/minimodem-rx-batch.patch -- this is "decode the
+ * next batch of files while the last streams of this one finish".
+ *
+ * HIP runs a process's streams on GPU_MAX_HW_QUEUES hardware queues (4 unless the environment
+ * said otherwise when the runtime started) and the null stream takes one: lanes beyond that
+ * would share a queue and run one behind the other, which measures slower than fewer lanes.
+ * The depth is therefore clamped to the queues there are; mifsk_pipeline_info_get says what
+ * was asked for, what is in effect and how many queues the runtime has.  (Export
+ * GPU_MAX_HW_QUEUES=8 before the first HIP call for a depth above 3.)
+ *
+ * Results are identical to mifsk_demod_batch's, pass for pass: a lane is an ordinary context
+ * and stream.  The calls are serialised per pipeline; submit never blocks on the device. */
+typedef struct mifsk_pipeline mifsk_pipeline;
+#define MIFSK_PIPELINE_MAX_DEPTH	8
+#define MIFSK_PIPELINE_NO_PRODUCER	((void *)(intptr_t)-1)
+
+typedef struct mifsk_pipeline_info {
+    uint32_t	depth_requested;
+    uint32_t	depth;		/* lanes in effect: min(requested, hw_queues - 1), at least 1 */
+    uint32_t	hw_queues;	/* GPU_MAX_HW_QUEUES as this process's environment has it (4: unset) */
+    uint32_t	output_sets;	/* `depth` once mifsk_pipeline_outputs_alloc has run, else 0 */
+} mifsk_pipeline_info;
+
+#define MIFSK_WANT_BYTES	1u
+#define MIFSK_WANT_BITS		2u
+#define MIFSK_WANT_FRAMES	4u
+#define MIFSK_WANT_EPISODES	8u
+
+/* device < 0: the current HIP device.  -ENODEV without a usable device. */
+int  mifsk_pipeline_create( mifsk_pipeline **out, int device, int depth );
+void mifsk_pipeline_destroy( mifsk_pipeline *p );	/* waits for what is in flight */
+int  mifsk_pipeline_info_get( const mifsk_pipeline *p, mifsk_pipeline_info *info );
+
+/* One set of output arrays per lane, for batches of up to `nstreams` streams: counts and status
+ * always, the arrays `want` names (MIFSK_WANT_*).  Replaces sets made before (after waiting for
+ * what is in flight).  mifsk_pipeline_outputs_get fills the output fields of *io (pointers and
+ * capacities, nothing else) with the set pass `ticket` writes or wrote. */
+int  mifsk_pipeline_outputs_alloc( mifsk_pipeline *p, int nstreams, size_t frames_cap,
+	size_t episodes_cap, unsigned want );
+int  mifsk_pipeline_outputs_get( mifsk_pipeline *p, uint64_t ticket, mifsk_demod_io *io );
+
+/* mifsk_demod_batch(cfg, io) as the pipeline's next pass; *ticket (may be NULL) receives its
+ * number (= mifsk_pipeline_next_ticket before the call).  `after`: the hipStream_t the batch
+ * was produced on -- the lane waits for the point that stream has reached now (NULL is the
+ * null stream) -- or MIFSK_PIPELINE_NO_PRODUCER.  An io without any output pointer is given the
+ * lane's own set (mifsk_pipeline_outputs_alloc).  The set a pass writes is the set pass
+ * ticket - depth wrote: whatever reads that one must be ordered before this submit -- on the
+ * lane's stream (mifsk_pipeline_stream: what a gather of the results is queued on), or by a
+ * mifsk_pipeline_wait. */
+int  mifsk_pipeline_submit( mifsk_pipeline *p, const mifsk_rx_config *cfg,
+	const mifsk_demod_io *io, void *after, uint64_t *ticket );
+uint64_t mifsk_pipeline_next_ticket( const mifsk_pipeline *p );
+/* the host waits until pass `ticket` is complete (and with it everything submitted on its lane
+ * up to now); -EINVAL for a ticket not yet issued */
+int  mifsk_pipeline_wait( mifsk_pipeline *p, uint64_t ticket );
+/* ... or `stream` does, on the device */
+int  mifsk_pipeline_join( mifsk_pipeline *p, uint64_t ticket, void *stream );
+/* everything submitted so far */
+int  mifsk_pipeline_drain( mifsk_pipeline *p );
+/* the lane of pass `ticket`: its hipStream_t and its context */
+void *mifsk_pipeline_stream( mifsk_pipeline *p, uint64_t ticket );
+mifsk_ctx *mifsk_pipeline_ctx( mifsk_pipeline *p, uint64_t ticket );
 
 /* What mifsk_demod_batch would launch for `cfg`, a batch of `nstreams` streams and
  * `flags` (MIFSK_IO_*): the kernel instantiation, its launch geometry and the

@@ -88,6 +88,16 @@ class Context:
     def device_name(self):
         return self._lib.mifsk_ctx_device_name(self.handle).decode()
 
+    def selftest_sqrt(self, nvalues, seed=1):
+        """mifsk_selftest_sqrt: the kernels' short square root against the exact sequence on
+        `nvalues` sums of squares -> (accepted and differing [must be 0], sent to the exact
+        sequence by the guard, differing without the guard, evaluated)."""
+        counts = (C.c_uint64 * 4)()
+        rc = self._lib.mifsk_selftest_sqrt(self.handle, int(seed), int(nvalues), counts)
+        if rc != 0:
+            raise RuntimeError("mifsk_selftest_sqrt failed: %d" % rc)
+        return tuple(int(c) for c in counts)
+
     def close(self):
         if self.handle:
             self._lib.mifsk_ctx_destroy(self.handle)
@@ -378,6 +388,148 @@ def gather_bytes(local_bytes, local_nbytes, dst=0, group=None):
     for w in dist.batch_isend_irecv(reqs):
         w.wait()
     return None, None
+
+
+class _DevArray:
+    """A device array the library owns, for torch.as_tensor (zero copy)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(int(x) for x in shape), "typestr": typestr,
+                                         "data": (int(ptr), False), "version": 2, "strides": None}
+
+
+class Pipeline:
+    """mifsk_pipeline_*: `depth` batches in flight behind the C ABI -- lanes of a context, a HIP
+    stream and a completion event each, and (outputs(...)) one set of output arrays per lane,
+    all owned by the library.  submit() is mifsk_demod_batch as the pipeline's next pass and
+    returns its ticket; pass t runs on lane t % depth.  Results are those of demod_batch.
+
+        pipe = M.Pipeline(device, depth=3)
+        pipe.outputs(nstreams, frames_cap, want=("bytes",))
+        t = pipe.submit(cfg, samples)            # ... more submits: they overlap on the device
+        pipe.wait(t); out = pipe.result(t)       # dict of torch views of that pass's set
+    """
+
+    def __init__(self, device=-1, depth=3):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        rc = self._lib.mifsk_pipeline_create(C.byref(h), int(device), int(depth))
+        if rc != 0:
+            raise RuntimeError("mifsk_pipeline_create failed: %d" % rc)
+        self.handle = h
+        info = _lib.PipelineInfo()
+        self._lib.mifsk_pipeline_info_get(self.handle, C.byref(info))
+        self.depth, self.depth_requested, self.hw_queues = int(info.depth), int(info.depth_requested), int(info.hw_queues)
+        self._views = {}
+        self._shape = None
+
+    def info(self):
+        info = _lib.PipelineInfo()
+        self._lib.mifsk_pipeline_info_get(self.handle, C.byref(info))
+        return {k: int(getattr(info, k)) for k, _ in info._fields_}
+
+    def outputs(self, nstreams, frames_cap, episodes_cap=8, want=("bytes",)):
+        flags = (_lib.WANT_BYTES if "bytes" in want else 0) | (_lib.WANT_BITS if "bits" in want else 0) | \
+            (_lib.WANT_FRAMES if "frames" in want else 0) | (_lib.WANT_EPISODES if "episodes" in want else 0)
+        rc = self._lib.mifsk_pipeline_outputs_alloc(self.handle, int(nstreams), int(frames_cap),
+                                                    int(episodes_cap), flags)
+        if rc != 0:
+            raise RuntimeError("mifsk_pipeline_outputs_alloc failed: %d" % rc)
+        self._views = {}
+        self._shape = (int(nstreams), int(frames_cap), int(episodes_cap))
+
+    def result(self, ticket):
+        """torch views (no copy, no synchronisation) of the output set pass `ticket` writes"""
+        lane = int(ticket) % self.depth
+        if lane in self._views:
+            return self._views[lane]
+        torch = _torch()
+        io = _lib.DemodIO()
+        rc = self._lib.mifsk_pipeline_outputs_get(self.handle, int(ticket), C.byref(io))
+        if rc != 0:
+            raise RuntimeError("no output sets: call outputs() first (%d)" % rc)
+        ns, fc, ec = self._shape
+        dev = torch.device("cuda", torch.cuda.current_device())
+
+        def view(ptr, shape, typestr, dtype):
+            return torch.as_tensor(_DevArray(ptr, shape, typestr), device=dev).view(dtype) if ptr else None
+        out = {"nframes": view(io.d_nframes, (ns,), "<i4", torch.int32),
+               "nbytes": view(io.d_nbytes, (ns,), "<i4", torch.int32),
+               "status": view(io.d_status, (ns,), "<i4", torch.int32)}
+        if io.d_bytes:
+            out["bytes"] = view(io.d_bytes, (ns, fc), "|u1", torch.uint8)
+        if io.d_bits:
+            out["bits"] = view(io.d_bits, (ns, fc), "<i8", torch.int64)
+        if io.d_frames:
+            out["frames"] = view(io.d_frames, (ns, fc, FRAME_DTYPE.itemsize), "|u1", torch.uint8)
+        if io.d_episodes:
+            out["episodes"] = view(io.d_episodes, (ns, int(io.episodes_cap), EPISODE_DTYPE.itemsize), "|u1", torch.uint8)
+            out["nepisodes"] = view(io.d_nepisodes, (ns,), "<i4", torch.int32)
+        self._views[lane] = out
+        return out
+
+    def submit(self, cfg, samples, nsamples=None, after="current", ring_exact=False, engine=None):
+        """`after`: the torch stream the batch was produced on ("current": torch's current
+        stream), or None when nothing has to be waited for."""
+        torch = _torch()
+        assert samples.is_cuda and samples.dtype == torch.float32 and samples.dim() == 2 and samples.stride(1) == 1
+        nstreams, width = samples.shape
+        _check_nsamples(torch, nsamples, nstreams)
+        assert nstreams > 1 or width % 4 == 0
+        io = _lib.DemodIO()
+        io.d_samples = samples.data_ptr()
+        io.stream_stride = samples.stride(0) if nstreams > 1 else int(width)
+        io.d_nsamples = nsamples.data_ptr() if nsamples is not None else None
+        io.nsamples = int(width)
+        io.nstreams = nstreams
+        io.flags = (_lib.IO_RING_EXACT if ring_exact else 0) | \
+            (_lib.IO_ENGINE_WORKGROUP if engine == "workgroup" else 0) | \
+            (_lib.IO_ENGINE_WAVE if engine == "wave" else 0)
+        if after == "current":
+            after = torch.cuda.current_stream()
+        prod = _lib.PIPELINE_NO_PRODUCER if after is None else C.c_void_p(after.cuda_stream)
+        t = C.c_uint64(0)
+        rc = self._lib.mifsk_pipeline_submit(self.handle, C.byref(cfg), C.byref(io), prod, C.byref(t))
+        if rc != 0:
+            raise RuntimeError("mifsk_pipeline_submit failed: %d" % rc)
+        return int(t.value)
+
+    def next_ticket(self):
+        return int(self._lib.mifsk_pipeline_next_ticket(self.handle))
+
+    def wait(self, ticket):
+        rc = self._lib.mifsk_pipeline_wait(self.handle, int(ticket))
+        if rc != 0:
+            raise RuntimeError("mifsk_pipeline_wait(%d) failed: %d" % (ticket, rc))
+
+    def join(self, ticket, stream=None):
+        """torch stream `stream` (default: the current one) waits for pass `ticket` on the device"""
+        torch = _torch()
+        rc = self._lib.mifsk_pipeline_join(self.handle, int(ticket), _stream_ptr(torch, stream))
+        if rc != 0:
+            raise RuntimeError("mifsk_pipeline_join(%d) failed: %d" % (ticket, rc))
+
+    def drain(self):
+        rc = self._lib.mifsk_pipeline_drain(self.handle)
+        if rc != 0:
+            raise RuntimeError("mifsk_pipeline_drain failed: %d" % rc)
+
+    def stream(self, ticket):
+        """the lane's HIP stream as a torch stream (what a gather of that pass's results is queued on)"""
+        torch = _torch()
+        return torch.cuda.ExternalStream(int(self._lib.mifsk_pipeline_stream(self.handle, int(ticket))))
+
+    def close(self):
+        if self.handle:
+            self._views = {}
+            self._lib.mifsk_pipeline_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class ByteGatherer:

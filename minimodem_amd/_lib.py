@@ -147,6 +147,13 @@ class LaunchInfo(C.Structure):
     ]
 
 
+class PipelineInfo(C.Structure):
+    _fields_ = [("depth_requested", C.c_uint32), ("depth", C.c_uint32),
+                ("hw_queues", C.c_uint32), ("output_sets", C.c_uint32)]
+
+
+WANT_BYTES, WANT_BITS, WANT_FRAMES, WANT_EPISODES = 1, 2, 4, 8
+PIPELINE_NO_PRODUCER = C.c_void_p(-1)
 IO_RING_EXACT = 1
 IO_ENGINE_WORKGROUP = 2
 IO_ENGINE_WAVE = 4
@@ -213,7 +220,11 @@ EXPORTS = [
     "mifsk_demod_batch_host_ex", "mifsk_host_alloc", "mifsk_host_free", "mifsk_max_episodes",
     "mifsk_demod_files", "mifsk_files_count", "mifsk_files_get", "mifsk_files_stats",
     "mifsk_files_free", "mifsk_demod_slab", "mifsk_scan_plan_get",
-    "mifsk_demod_slab_ring", "mifsk_ring_floats",
+    "mifsk_demod_slab_ring", "mifsk_ring_floats", "mifsk_selftest_sqrt",
+    "mifsk_pipeline_create", "mifsk_pipeline_destroy", "mifsk_pipeline_info_get",
+    "mifsk_pipeline_outputs_alloc", "mifsk_pipeline_outputs_get", "mifsk_pipeline_submit",
+    "mifsk_pipeline_next_ticket", "mifsk_pipeline_wait", "mifsk_pipeline_join",
+    "mifsk_pipeline_drain", "mifsk_pipeline_stream", "mifsk_pipeline_ctx",
 ]
 
 _lib = None
@@ -333,5 +344,32 @@ def load():
                                           C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.mifsk_ring_floats.restype = C.c_size_t
     lib.mifsk_ring_floats.argtypes = [C.POINTER(RxConfig)]
+    lib.mifsk_pipeline_create.restype = C.c_int
+    lib.mifsk_pipeline_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int]
+    lib.mifsk_pipeline_destroy.restype = None
+    lib.mifsk_pipeline_destroy.argtypes = [C.c_void_p]
+    lib.mifsk_pipeline_info_get.restype = C.c_int
+    lib.mifsk_pipeline_info_get.argtypes = [C.c_void_p, C.POINTER(PipelineInfo)]
+    lib.mifsk_pipeline_outputs_alloc.restype = C.c_int
+    lib.mifsk_pipeline_outputs_alloc.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_uint]
+    lib.mifsk_pipeline_outputs_get.restype = C.c_int
+    lib.mifsk_pipeline_outputs_get.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(DemodIO)]
+    lib.mifsk_pipeline_submit.restype = C.c_int
+    lib.mifsk_pipeline_submit.argtypes = [C.c_void_p, C.POINTER(RxConfig), C.POINTER(DemodIO), C.c_void_p,
+                                          C.POINTER(C.c_uint64)]
+    lib.mifsk_pipeline_next_ticket.restype = C.c_uint64
+    lib.mifsk_pipeline_next_ticket.argtypes = [C.c_void_p]
+    lib.mifsk_pipeline_wait.restype = C.c_int
+    lib.mifsk_pipeline_wait.argtypes = [C.c_void_p, C.c_uint64]
+    lib.mifsk_pipeline_join.restype = C.c_int
+    lib.mifsk_pipeline_join.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+    lib.mifsk_pipeline_drain.restype = C.c_int
+    lib.mifsk_pipeline_drain.argtypes = [C.c_void_p]
+    lib.mifsk_pipeline_stream.restype = C.c_void_p
+    lib.mifsk_pipeline_stream.argtypes = [C.c_void_p, C.c_uint64]
+    lib.mifsk_pipeline_ctx.restype = C.c_void_p
+    lib.mifsk_pipeline_ctx.argtypes = [C.c_void_p, C.c_uint64]
+    lib.mifsk_selftest_sqrt.restype = C.c_int
+    lib.mifsk_selftest_sqrt.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
     _lib = lib
     return lib

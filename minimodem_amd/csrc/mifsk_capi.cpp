@@ -367,6 +367,7 @@ extern "C" size_t mifsk_abi_sizeof( const char *name )
     MIFSK_SIZEOF(mifsk_episode);
     MIFSK_SIZEOF(mifsk_demod_io);
     MIFSK_SIZEOF(mifsk_launch_info);
+    MIFSK_SIZEOF(mifsk_pipeline_info);
     MIFSK_SIZEOF(mifsk_scan_plan);
     MIFSK_SIZEOF(mifsk_host_stats);
     MIFSK_SIZEOF(mifsk_stream_state);
@@ -375,6 +376,29 @@ extern "C" size_t mifsk_abi_sizeof( const char *name )
     MIFSK_SIZEOF(fsk_plan);
 #undef MIFSK_SIZEOF
     return 0;
+}
+
+extern "C" int mifsk_selftest_sqrt( mifsk_ctx *ctx, uint64_t seed, uint64_t nvalues, uint64_t counts[4] )
+{
+    if ( !ctx || !counts )
+	return -EINVAL;
+    HIP_OK(hipSetDevice(ctx->device));
+    unsigned long long *d = nullptr;
+    HIP_OK(hipMalloc(&d, 4 * sizeof(unsigned long long)));
+    int rc = hipMemset(d, 0, 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : -EIO;
+    const uint32_t per_thread = 4096;
+    uint64_t blocks = ( nvalues + 256ull * per_thread - 1 ) / ( 256ull * per_thread );
+    if ( blocks < 1 ) blocks = 1;
+    if ( blocks > 0x7FFFFFFFull ) blocks = 0x7FFFFFFFull;
+    if ( rc == 0 )
+	rc = mifsk::launch_selftest_sqrt(seed, (uint32_t)blocks, per_thread, d, nullptr);
+    unsigned long long h[4] = { 0, 0, 0, 0 };
+    if ( rc == 0 && hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess )
+	rc = -EIO;
+    (void)hipFree(d);
+    for ( int i = 0; i < 4; i++ )
+	counts[i] = h[i];
+    return rc;
 }
 
 extern "C" int mifsk_ctx_create( mifsk_ctx **out, int device )

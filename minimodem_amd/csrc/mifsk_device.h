@@ -239,6 +239,9 @@ int launch_detect_carrier( const float *d_samples, unsigned nsamples,
 	const double *d_cs /* [fftsize][2] */, unsigned fftsize, unsigned nbands,
 	float *d_mags /* [nbands] */, void *stream );
 
+// self-test of the short square root of band_mag2() (mifsk_kernels.hip); d_out: four counters
+int launch_selftest_sqrt( uint64_t seed, uint32_t blocks, uint32_t per_thread, unsigned long long *d_out, void *stream );
+
 // Tuning overrides for experiments (MIFSK_ENGINE, MIFSK_WAVES_PER_CU, MIFSK_SV,
 // MIFSK_LDS_PAD, MIFSK_LAT_ROUNDS, MIFSK_CHAIN): honoured only when MIFSK_EXPERIMENT is set in the
 // environment, so that a stray variable cannot change what production launches.

@@ -809,6 +809,71 @@ __device__ __forceinline__ void replay_scan_soft( float &xt, float &xpk, float &
 #undef MIFSK_SOFT_STEP
 }
 
+// ... and where the running peak is DEAD.  With a carrier-held search step of one sample the
+// refine rule never searches (minimodem.c:1357 wants try_step_nsamples > 1) and sets no flag:
+// peak_confidence is then read by nothing but its own update (:1278-1282,1392-1393) -- no
+// predicate, no output, no episode total depends on it.  A call that keeps no loop state for a
+// later one (one launch = whole streams) leaves it out: the amplitude tracker alone, two
+// instructions per frame instead of six (and the two running sums when episode totals are
+// wanted).  xpk / bpk are left as they came in.
+__device__ __forceinline__ void replay_scan_track( float &xt, float &xsc, float &xsa,
+	float &bt, float &bsc, float &bsa, float cv, float av, uint32_t K, bool totals )
+{
+    float yt = xt, ysc = xsc, ysa = xsa;
+    float tmp = xt + xt;
+    uint32_t n = K / 2u;			// 2 * pairs >= K - 1 steps
+    if ( !totals ) {
+#define MIFSK_TRACK_STEP(ST, DT)										\
+	"v_add_f32_dpp %[tmp], " ST ", %[av] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"		\
+	"v_mul_f32_e32 " DT ", 0.5, %[tmp]\n\t"								\
+	"s_nop 1\n\t"		/* DT is read through DPP by the next step: two wait states */
+	asm volatile(
+	    "s_nop 1\n\t"
+	    "s_cmp_eq_u32 %[n], 0\n\t"
+	    "s_cbranch_scc1 2f\n\t"
+	    "1:\n\t"
+	    MIFSK_TRACK_STEP("%[xt]", "%[yt]")
+	    "s_sub_u32 %[n], %[n], 1\n\t"
+	    MIFSK_TRACK_STEP("%[yt]", "%[xt]")
+	    "s_cmp_lg_u32 %[n], 0\n\t"
+	    "s_cbranch_scc1 1b\n\t"
+	    "2:\n\t"
+	    "v_mov_b32_dpp %[bt], %[xt] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+	    "s_nop 1\n\t"
+	    : [bt] "+v"(bt), [xt] "+v"(xt), [yt] "+v"(yt), [tmp] "+v"(tmp), [n] "+s"(n)
+	    : [av] "v"(av)
+	    : "scc");
+#undef MIFSK_TRACK_STEP
+	return;
+    }
+#define MIFSK_TRACK_STEP_T(ST, SSC, SSA, DT, DSC, DSA)							\
+	"v_add_f32_dpp %[tmp], " ST ", %[av] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"		\
+	"v_add_f32_dpp " DSC ", " SSC ", %[cv] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"		\
+	"v_mul_f32_e32 " DT ", 0.5, %[tmp]\n\t"								\
+	"v_add_f32_dpp " DSA ", " SSA ", %[av] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"		\
+	"s_nop 1\n\t"		/* DT, DSA: two wait states before the next step reads them through DPP */
+    asm volatile(
+	"s_nop 1\n\t"
+	"s_cmp_eq_u32 %[n], 0\n\t"
+	"s_cbranch_scc1 2f\n\t"
+	"1:\n\t"
+	MIFSK_TRACK_STEP_T("%[xt]", "%[xsc]", "%[xsa]", "%[yt]", "%[ysc]", "%[ysa]")
+	"s_sub_u32 %[n], %[n], 1\n\t"
+	MIFSK_TRACK_STEP_T("%[yt]", "%[ysc]", "%[ysa]", "%[xt]", "%[xsc]", "%[xsa]")
+	"s_cmp_lg_u32 %[n], 0\n\t"
+	"s_cbranch_scc1 1b\n\t"
+	"2:\n\t"
+	"v_mov_b32_dpp %[bt], %[xt] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+	"v_mov_b32_dpp %[bsc], %[xsc] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+	"v_mov_b32_dpp %[bsa], %[xsa] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+	"s_nop 1\n\t"
+	: [bt] "+v"(bt), [bsc] "+v"(bsc), [bsa] "+v"(bsa), [xt] "+v"(xt), [xsc] "+v"(xsc), [xsa] "+v"(xsa),
+	  [yt] "+v"(yt), [ysc] "+v"(ysc), [ysa] "+v"(ysa), [tmp] "+v"(tmp), [n] "+s"(n)
+	: [cv] "v"(cv), [av] "v"(av)
+	: "scc");
+#undef MIFSK_TRACK_STEP_T
+}
+
 // maximum of v over the wave's 64 lanes (NaN never wins: v_max_f32 returns the other operand),
 // as a DPP reduction: row_shr 1, 2, 3 / 4 / 8 within each row of 16, then row_bcast 15 and 31
 // across the rows; the result is lane 63's.  (A loop of v_readlane + compare + branch over a

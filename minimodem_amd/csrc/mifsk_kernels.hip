@@ -116,8 +116,7 @@ void find_frame_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 		si = fma(xd, t[3], si);
 	    }
 	    if ( active )
-		s_mags[w] = make_float2(band_mag(mr, mi, cfg.magscalar),
-					band_mag(sr, si, cfg.magscalar));
+		s_mags[w] = band_mag2(mr, mi, sr, si, cfg.magscalar);
 	}
 	__syncthreads();
 	if ( lane < Q ) {
@@ -308,8 +307,7 @@ __device__ __forceinline__ void par_correlate( const DevCfg &cfg, const double *
 	    }
 	}
 	if ( active )
-	    lds->mags[0][w] = make_float2(band_mag(acc[0], acc[1], cfg.magscalar),
-					  band_mag(acc[2], acc[3], cfg.magscalar));
+	    lds->mags[0][w] = band_mag2(acc[0], acc[1], acc[2], acc[3], cfg.magscalar);
     }
 }
 
@@ -658,11 +656,9 @@ struct Master {
 #undef MIFSK_SOLO2_QUAD
 #undef MIFSK_SOLO2_SAMPLE
 	    if ( lane < nwin )
-		sm[lane] = make_float2(band_mag(accA[0], accA[1], cfg.magscalar),
-				       band_mag(accA[2], accA[3], cfg.magscalar));
+		sm[lane] = band_mag2(accA[0], accA[1], accA[2], accA[3], cfg.magscalar);
 	    if ( lane + 64u < nwin )
-		sm[lane + 64u] = make_float2(band_mag(accB[0], accB[1], cfg.magscalar),
-					     band_mag(accB[2], accB[3], cfg.magscalar));
+		sm[lane + 64u] = band_mag2(accB[0], accB[1], accB[2], accB[3], cfg.magscalar);
 	}
 	wave_lds_sync();
 	const uint32_t t_sf2 = MIFSK_CLOCK();
@@ -1594,8 +1590,7 @@ __device__ __forceinline__ void worker_lattice_linear( const WorkerHot &h, const
 	    mr = acc[0]; mi = acc[1]; sr = acc[2]; si = acc[3];
 	}
 	if ( active )
-	    lds->mags[buf][win_base + w] = make_float2(band_mag(mr, mi, h.magscalar),
-							   band_mag(sr, si, h.magscalar));
+	    lds->mags[buf][win_base + w] = band_mag2(mr, mi, sr, si, h.magscalar);
 	wave_lds_sync();			// the region is rewritten by the next round
 	const uint32_t t_out = MIFSK_CLOCK();
 	wcyc[0] += t_mid - t_in;
@@ -1654,8 +1649,7 @@ __device__ __forceinline__ void worker_lattice_direct( const DevCfg &cfg, const 
 	}
     }
     if ( active )
-	lds->mags[cmd->buf][win_base + w] = make_float2(band_mag(acc[0], acc[1], cfg.magscalar),
-						       band_mag(acc[2], acc[3], cfg.magscalar));
+	lds->mags[cmd->buf][win_base + w] = band_mag2(acc[0], acc[1], acc[2], acc[3], cfg.magscalar);
     wcyc[1] += MIFSK_CLOCK() - t_in;
 }
 
@@ -1832,6 +1826,71 @@ void spectrum_kernel( const float *__restrict__ x, uint32_t nsamples,
     }
     const float magscalar = 1.0f / ( (float)nsamples / 2.0f );	// fsk.c:553
     mags[b] = band_mag(re, im, magscalar);
+}
+
+// ---------------------------------------------------------------------------
+// kernel 4: self-test of band_mag2()'s short square root against the exact sequence
+// (mifsk_selftest_sqrt; tests/test_gpu_math.py).  Thread t of `total` evaluates `per_thread`
+// sums of squares: pseudo-random pairs of floats (every exponent alike, as hypotf_check.c), and
+// -- every other value -- doubles placed within a few hundred units in the last place of a
+// float rounding boundary, where the two paths could part.  out[0]: values whose short path
+// was taken as safe and differs from the exact one (must be 0); out[1]: values the guard sent
+// to the exact sequence; out[2]: values whose UNGUARDED short result differs (what the guard is
+// for); out[3]: values evaluated.
+// ---------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256)
+void selftest_sqrt_kernel( uint64_t seed, uint32_t per_thread, unsigned long long *out )
+{
+    uint64_t st = seed + 0x9E3779B97F4A7C15ull * ( (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + 1u );
+    auto next = [&]() -> uint64_t {
+	uint64_t z = ( st += 0x9E3779B97F4A7C15ull );
+	z = ( z ^ ( z >> 30 ) ) * 0xBF58476D1CE4E5B9ull;
+	z = ( z ^ ( z >> 27 ) ) * 0x94D049BB133111EBull;
+	return z ^ ( z >> 31 );
+    };
+    uint32_t bad = 0, guarded = 0, raw_bad = 0;
+    for ( uint32_t i = 0; i < per_thread; i++ ) {
+	const uint64_t r = next();
+	double s;
+	if ( i & 1u ) {
+	    // the square of a point within +-600 units (of the double's last place) of the midpoint
+	    // between float f and its upper neighbour, rounded to double: sqrt lands about there
+	    uint32_t fb = (uint32_t)r & 0x7FFFFFFFu;
+	    if ( ( fb & 0x7F800000u ) == 0x7F800000u ) fb ^= 0x00800000u;
+	    const float f = __uint_as_float(fb);
+	    const float fn = __uint_as_float(fb + 1u);
+	    const double mid = 0.5 * ( (double)f + (double)fn );
+	    const long long off = (long long)( ( r >> 32 ) % 1201u ) - 600;
+	    const double m = __longlong_as_double(__double_as_longlong(mid) + off);
+	    s = m * m;
+	} else {
+	    uint32_t a = (uint32_t)r & 0x7FFFFFFFu, b = (uint32_t)( r >> 32 ) & 0x7FFFFFFFu;
+	    // (non-finite inputs now and then: the range test must send them to the exact path)
+	    const float fa = __uint_as_float(a), fbv = __uint_as_float(b);
+	    s = __builtin_fma((double)fa, (double)fa, (double)fbv * (double)fbv);
+	}
+	bool unsafe;
+	const float quick = (float)sqrt_newton1(s, unsafe);
+	const float exact = (float)sqrt_sumsq(s);
+	const bool differ = __float_as_uint(quick) != __float_as_uint(exact) && !( quick != quick && exact != exact );
+	if ( unsafe )
+	    guarded++;
+	else if ( differ )
+	    bad++;
+	if ( differ )
+	    raw_bad++;
+    }
+    atomicAdd(&out[0], (unsigned long long)bad);
+    atomicAdd(&out[1], (unsigned long long)guarded);
+    atomicAdd(&out[2], (unsigned long long)raw_bad);
+    atomicAdd(&out[3], (unsigned long long)per_thread);
+}
+
+int launch_selftest_sqrt( uint64_t seed, uint32_t blocks, uint32_t per_thread, unsigned long long *d_out, void *stream )
+{
+    hipLaunchKernelGGL(selftest_sqrt_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, seed, per_thread, d_out);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
 // ---------------------------------------------------------------------------

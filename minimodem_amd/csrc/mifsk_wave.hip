@@ -363,8 +363,7 @@ struct Wave {
 	    else
 		corr_lds_stream(tw, slab + rel, nq, lane, acc);
 	    if ( active )
-		mags[w] = make_float2(band_mag(acc[0], acc[1], cfg.magscalar),
-				      band_mag(acc[2], acc[3], cfg.magscalar));
+		mags[w] = band_mag2(acc[0], acc[1], acc[2], acc[3], cfg.magscalar);
 	}
 	wave_lds_sync();			// the slab is rewritten by the next round
 	cyc_corr += MIFSK_WCLOCK() - t_mid;
@@ -402,7 +401,7 @@ struct Wave {
 	    }
 	}
 	if ( active )
-	    mags[w] = make_float2(band_mag(acc[0], acc[1], cfg.magscalar), band_mag(acc[2], acc[3], cfg.magscalar));
+	    mags[w] = band_mag2_exact(acc[0], acc[1], acc[2], acc[3], cfg.magscalar);
     }
 
     // Evaluate F lattice frames anchored at A (first-try position of frame 0).
@@ -578,8 +577,7 @@ struct Wave {
 		}
 	    }
 	    if ( active )
-		mags[w] = make_float2(band_mag(acc[0], acc[1], cfg.magscalar),
-				      band_mag(acc[2], acc[3], cfg.magscalar));
+		mags[w] = band_mag2_exact(acc[0], acc[1], acc[2], acc[3], cfg.magscalar);
 	}
     }
 
@@ -836,7 +834,7 @@ struct Wave {
 			     && (float)( si - delta ) == (float)( si + delta );
 	    const bool wanted = active && j >= c0;
 	    if ( wanted && stable )
-		mags[( j - c0 ) * nb + k] = make_float2(band_mag(mr, mi, cfg.magscalar), band_mag(sr, si, cfg.magscalar));
+		mags[( j - c0 ) * nb + k] = band_mag2_exact(mr, mi, sr, si, cfg.magscalar);
 	    const unsigned long long again = __ballot(wanted && !stable);
 	    if ( g0 == 0u )
 		redo0 = again;
@@ -863,8 +861,7 @@ struct Wave {
 	    double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
 	    corr_global_tiled(tw, x, a, nredo, B, lane, slab, acc);
 	    if ( lane < nredo )
-		mags[( j - c0 ) * nb + k] = make_float2(band_mag(acc[0], acc[1], cfg.magscalar),
-							   band_mag(acc[2], acc[3], cfg.magscalar));
+		mags[( j - c0 ) * nb + k] = band_mag2_exact(acc[0], acc[1], acc[2], acc[3], cfg.magscalar);
 	    wave_lds_sync();
 	}
 	cyc_g_redo += MIFSK_WCLOCK() - tg2;
@@ -1309,7 +1306,10 @@ void demod_wave_kernel( const DevCfg *__restrict__ cfgp, const double *__restric
 		float xsa = amplitude_total + av;
 		float my_t = track_amplitude, my_pk = peak_confidence;
 		float my_sc = confidence_total, my_sa = amplitude_total;
-		if ( soft )
+		// (soft, and no loop state kept for a later call: the running peak is read by nothing)
+		if ( soft && !ST )
+		    replay_scan_track(xt, xsc, xsa, my_t, my_sc, my_sa, cv, av, K, want_totals);
+		else if ( soft )
 		    replay_scan_soft(xt, xpk, xsc, xsa, my_t, my_pk, my_sc, my_sa, cv, av, K, lane, want_totals);
 		else
 		    replay_scan_asm(xt, xpk, xsc, xsa, my_t, my_pk, my_sc, my_sa, cv, av, K, want_totals);

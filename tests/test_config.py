@@ -98,7 +98,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS), (declared ^ set(_lib.EXPORTS))
     for name in sorted(declared):
         assert hasattr(lib, name), name
-    assert lib.mifsk_abi_version() == 7
+    assert lib.mifsk_abi_version() == 8
 
 
 def test_scan_plans_cover_their_windows():
@@ -158,7 +158,7 @@ def test_struct_layouts_match_between_bindings():
     lib = _lib.load()
     mirror = {"mifsk_modem_args": _lib.ModemArgs, "mifsk_rx_config": _lib.RxConfig, "mifsk_search": _lib.Search,
               "mifsk_search_result": _lib.SearchResult, "mifsk_demod_io": _lib.DemodIO,
-              "mifsk_launch_info": _lib.LaunchInfo, "mifsk_scan_plan": _lib.ScanPlan,
+              "mifsk_launch_info": _lib.LaunchInfo, "mifsk_pipeline_info": _lib.PipelineInfo, "mifsk_scan_plan": _lib.ScanPlan,
               "mifsk_host_stats": _lib.HostStats, "mifsk_wav_info": _lib.WavInfo,
               "mifsk_file_result": _lib.FileResult, "fsk_plan": _lib.FskPlan}
     for name, t in mirror.items():
