@@ -26,18 +26,23 @@ the next step).  Streams shard across ranks with no data-path collective.
 the job's total fixed (8 x the per-GPU batch: 65536 streams for --config 12000,
 the size BASELINE.json states) and divides it over the ranks.
 
-Timing: before the W warm-up passes the kernel is launched untimed for
-0.3 s (`--preheat-ms`: the first launches after host-side set-up run at idle clocks, and the
-driver's K = 20 is 7-11 ms of GPU work); the K timed passes keep three or four passes in flight
-(`--pipeline`: pass i on HIP stream i mod P with its own context, its own copy of the batch and
-its own outputs, so that it fills the CUs the late streams of pass i - 1 leave idle), bracketed
-by barrier + synchronize as the contract says; `roofline` is the kernel launched SERIALLY on one
-stream (K launches between the preheat and the warm-up passes, one event pair around them).
+Timing: first of all K launches are timed COLD (`cold_ms_per_step`: what a
+25-launch job sees right after host-side set-up); then the kernel is launched untimed for 0.3 s
+(`--preheat-ms`: the first launches after set-up run at idle clocks, and the driver's K = 20 is
+7-11 ms of GPU work); then K launches SERIALLY on one stream, one event pair around them
+(`roofline.*`, `value_serial`); then the W warm-up and the K timed passes go through the library's
+pipeline (mifsk_pipeline_*, `--pipeline` P: pass i on lane i mod P -- a context, a HIP stream and
+an output set of the library's own -- so that it fills the CUs the late streams of pass i - 1
+leave idle), bracketed by barrier + synchronize as the contract says (`value`, `ms_per_step`).
 
 Prints ONE JSON line on rank 0 (contract in the task description), including
   roofline     : HBM-read roofline of the demod kernel, measured live with
                  events on the launch stream (serial launches, see above)
-  pipeline     : passes in flight, ms per pass and fraction of 8 TB/s of the timed passes
+  value_serial : samples / roofline.kernel_ms_avg -- one batch at a time, no overlap
+  cold_ms_per_step : K serial launches before any preheat
+  pipeline     : passes in flight (asked for / in effect / hardware queues), ms per pass and
+                 fraction of 8 TB/s of the timed passes; every output set verified
+  small_batch  : configs[1] at 64 / 256 / 512 streams, launched serially (the chain-bound regime)
   preheat      : the untimed launches before the warm-up
   cpu_baseline : the reference's own CPU path (oracle/_ref: unmodified
                  src/*.c + FFT shim), one process per host core, on a bounded
@@ -46,7 +51,6 @@ Prints ONE JSON line on rank 0 (contract in the task description), including
                  full batch (1200) or a bounded sample, output compared with the GPU's
 """
 import argparse
-import contextlib
 import hashlib
 import json
 import os
@@ -166,7 +170,7 @@ def _ref_decode(args):
     return r.stdout
 
 
-def cpu_baselines(name, mode, sample_rate, host, lens, gpu_bytes, gpu_nbytes, gpu_text, budget_s=18.0):
+def cpu_baselines(name, mode, sample_rate, host, lens, gpu_bytes, gpu_nbytes, gpu_text, budget_s=18.0, port=True):
     """Rank 0, N=1 only.  Times the CPU checkers on this box's host cores on `host` (float32
     [k, n]: the first k streams of the batch) and cross-checks their output against the GPU's
     (gpu_text[i] = what the GPU path prints for stream i: device frame bits through the host
@@ -178,21 +182,22 @@ def cpu_baselines(name, mode, sample_rate, host, lens, gpu_bytes, gpu_nbytes, gp
     ncores = os.cpu_count() or 1
 
     # (1) the oracle restatement, one core
-    t0 = time.perf_counter()
-    mismatches, nsamp = 0, 0
-    for i in range(host.shape[0]):
-        r = O.oracle_rx_stream(ocfg, host[i, :lens[i]], ring_mode=False)
-        nsamp += int(lens[i])
-        if r["bytes"] != gpu_bytes[i, :gpu_nbytes[i]].tobytes():
-            mismatches += 1
-    dt = time.perf_counter() - t0
-    out["cpu_port"] = {
-        "value": nsamp / dt, "unit": "samples/s", "cores": 1, "kind": "port",
-        "sample": "first %d streams (%d samples) through oracle/fsk_oracle.c (direct 2-bin DFT, f64 fma), "
-                  "1 thread; decoded bytes compared with the GPU's: %d mismatching streams"
-                  % (host.shape[0], nsamp, mismatches),
-        "seconds": dt, "mismatching_streams": mismatches,
-    }
+    if port or not O.have_ref():
+        t0 = time.perf_counter()
+        mismatches, nsamp = 0, 0
+        for i in range(host.shape[0]):
+            r = O.oracle_rx_stream(ocfg, host[i, :lens[i]], ring_mode=False)
+            nsamp += int(lens[i])
+            if r["bytes"] != gpu_bytes[i, :gpu_nbytes[i]].tobytes():
+                mismatches += 1
+        dt = time.perf_counter() - t0
+        out["cpu_port"] = {
+            "value": nsamp / dt, "unit": "samples/s", "cores": 1, "kind": "port",
+            "sample": "first %d streams (%d samples) through oracle/fsk_oracle.c (direct 2-bin DFT, f64 fma), "
+                      "1 thread; decoded bytes compared with the GPU's: %d mismatching streams"
+                      % (host.shape[0], nsamp, mismatches),
+            "seconds": dt, "mismatching_streams": mismatches,
+        }
 
     # (2) the reference program itself (unmodified src/*.c + shims), one process per core,
     # on as many streams as fit the time budget (calibrated on the first few)
@@ -285,7 +290,15 @@ def agree(torch, dist, err, what):
         raise RankFailed("%s: %s" % (what, repr(err) if err is not None else "another rank failed"))
 
 
-_LANES = []
+_PIPES = {}
+
+
+def get_pipeline(M, torch, depth):
+    """one pipeline per depth and process (lanes made anew for every workload end up sharing
+    hardware queues)"""
+    if depth not in _PIPES:
+        _PIPES[depth] = M.Pipeline(torch.cuda.current_device(), depth=depth)
+    return _PIPES[depth]
 
 
 def run_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, cpu_leg, oracle_leg=True):
@@ -330,27 +343,23 @@ def run_workload(name, args, M, torch, dist, ctx, rank, world, steps, warmup, cp
     # against its body -- K = 20, each lane on its own copy of the batch: 2, 3, 4, 5 in flight
     # give 0.351, 0.351, 0.355, 0.357 ms per pass on configs[1] -- four where the launches are
     # long serial chains or chained dispatches: 1200noise 0.90 -> 0.77, SAME 7.7 -> 7.3 ms)
-    pipe = int(args.pipeline) if args.pipeline > 0 else {"1200": 3, "12000": 3}.get(name, 4)
-    lanes = None
+    asked = int(args.pipeline) if args.pipeline > 0 else {"1200": 3, "12000": 3}.get(name, 4)
+    pipe = None
     try:
-        # (made once per process and shared by the workloads: HIP multiplexes streams onto a few
-        # hardware queues, and lanes created anew for every workload end up sharing one)
-        while len(_LANES) < pipe:
-            _LANES.append((ctx if not _LANES else M.Context(torch.cuda.current_device()), torch.cuda.Stream()))
-        ctxs = [c for c, _ in _LANES[:pipe]]
-        streams = [None] if pipe == 1 else [s for _, s in _LANES[:pipe]]
-        # every lane reads a copy of the batch of its own: three batches in flight, not three
-        # readers of one (no pass can find another's samples in a cache)
-        copies = [samples] + [samples.clone() for _ in range(pipe - 1)]
-        torch.cuda.synchronize()
-        bufs = [M.demod_batch(ctxs[k % pipe], cfg, copies[k % pipe], stream=streams[k % pipe], **kw)
-                for k in range(max(2, pipe))]
-        lanes = (ctxs, streams, copies)
+        # The library's pipeline (mifsk_pipeline_*): lanes, streams and one output set per lane are
+        # its own; every pass reads the ONE resident batch (a copy per lane measures the same:
+        # profiles/r05_history.md section 6).  The first launch (module load, tables) happens here.
+        pipe = get_pipeline(M, torch, asked)
+        pipe.outputs(nstreams, frames_cap, episodes_cap=8, want=want)
+        bufs = [M.demod_batch(ctx, cfg, samples, **kw)]		# the serial launches' output set
+        for _ in range(pipe.depth):
+            pipe.submit(cfg, samples, nsamples=lens, engine=args.engine)
+        pipe.drain()
         torch.cuda.synchronize()
     except Exception as e:				# noqa: BLE001
         setup_err = e
     agree(torch, dist, setup_err, "%s: first launch" % name)
-    return timed_workload(name, args, M, torch, dist, ctx, lanes, rank, world, steps, warmup, cpu_leg, oracle_leg,
+    return timed_workload(name, args, M, torch, dist, ctx, pipe, rank, world, steps, warmup, cpu_leg, oracle_leg,
                           cfg, mode, entry, samples, lens, bufs, kw, payloads, lo, nstreams, nsamp, stride,
                           frames_cap, total_streams, total_samples_local)
 
@@ -445,18 +454,18 @@ def work_counters(name, M, torch, ctx, cfg, samples, lens, kw):
         return None
 
 
-def timed_workload(name, args, M, torch, dist, ctx, lanes, rank, world, steps, warmup, cpu_leg, oracle_leg,
+def timed_workload(name, args, M, torch, dist, ctx, pipeline, rank, world, steps, warmup, cpu_leg, oracle_leg,
                    cfg, mode, entry, samples, lens, bufs, kw, payloads, lo, nstreams, nsamp, stride,
                    frames_cap, total_streams, total_samples_local):
-    ctxs, streams, copies = lanes
-    pipe = len(ctxs)
-    nbuf = len(bufs)				# = max(2, pipe): pass i writes set i mod nbuf
+    pipe = pipeline.depth			# lanes in effect (asked for: pipeline.depth_requested)
+    nbuf = pipe					# pass t writes the library's set t % depth
     pending = [None] * nbuf
     # what a stream can decode at most is known on the host (its length): the gather ships
     # that many columns, not the whole frames_cap-wide buffer
     cols = int(M.max_frames(cfg, nsamp if lens is None else int(lens.max())))
     rows = [M.shard_range(total_streams, r, world)[1] - M.shard_range(total_streams, r, world)[0] for r in range(world)]
-    gatherer = M.ByteGatherer(dist, rank, world, cols=min(cols, frames_cap), rows=rows, slots=nbuf)
+    gatherer = M.ByteGatherer(dist, rank, world, cols=min(cols, frames_cap), rows=rows, slots=max(2, nbuf),
+                              loopback=args.gather_self and world == 1)
     failure = [None]
     wait_s = [0.0]
 
@@ -466,36 +475,49 @@ def timed_workload(name, args, M, torch, dist, ctx, lanes, rank, world, steps, w
             w.wait()
         wait_s[0] += time.perf_counter() - t
 
-    issued = [0]
 
-    def step(i, events=None):
-        b = i % nbuf
-        lane = i % pipe
-        # (everything of this pass is ordered on its lane's stream: the wait for the gather
-        # that last read this output set, the launch, the next gather's sends)
-        with torch.cuda.stream(streams[lane]) if streams[lane] is not None else contextlib.nullcontext():
-            if pending[b] is not None:		# its buffers are about to be overwritten
-                wait_all(pending[b])
-                pending[b] = None
-            if events is not None:
-                events[0].record()
-            try:
-                M.demod_batch(ctxs[lane], cfg, copies[lane], stream=streams[lane], out=bufs[b], **kw)
-            except Exception as e:		# noqa: BLE001 -- this rank still joins every gather
-                failure[0] = failure[0] or e
-            if events is not None:
-                events[1].record()
-            if world > 1:
-                # decoded bytes -> rank 0, grouped send/recv (each peer uses its own xGMI link)
-                pending[b] = gatherer.start(bufs[b]["bytes"], bufs[b]["nbytes"])
-        issued[0] = i + 1
+    gather_on = world > 1 or args.gather_self
+
+    def step(i):
+        tk = pipeline.next_ticket()
+        b = tk % nbuf
+        # (everything of this pass is ordered on its lane's stream: the gather that last read
+        # this output set, the launch, the next gather's sends)
+        if pending[b] is not None:		# its buffers are about to be overwritten
+            wait_all(pending[b])
+            pending[b] = None
+        try:
+            pipeline.submit(cfg, samples, nsamples=lens, after=None, engine=args.engine)
+        except Exception as e:			# noqa: BLE001 -- this rank still joins every gather
+            failure[0] = failure[0] or e
+            return
+        if gather_on:
+            # decoded bytes -> rank 0, grouped send/recv (each peer uses its own xGMI link),
+            # queued on the lane's stream behind the pass
+            out = pipeline.result(tk)
+            with torch.cuda.stream(pipeline.stream(tk)):
+                pending[b] = gatherer.start(out["bytes"], out["nbytes"])
 
     def drain():
-        for k in range(nbuf):			# oldest first
-            b = (issued[0] + k) % nbuf
+        for b in range(nbuf):
             if pending[b] is not None:
                 wait_all(pending[b])
                 pending[b] = None
+        pipeline.drain()
+
+    # COLD: K serial launches as the first thing after set-up (the state a short job finds the
+    # device in: the first launches after idling run at idle clocks), by the host's clock
+    cold_ms = None
+    if failure[0] is None:
+        try:
+            torch.cuda.synchronize()
+            tc = time.perf_counter()
+            for _ in range(steps):
+                M.demod_batch(ctx, cfg, samples, out=bufs[0], **kw)
+            torch.cuda.synchronize()
+            cold_ms = (time.perf_counter() - tc) * 1e3 / max(1, steps)
+        except Exception as e:			# noqa: BLE001
+            failure[0] = e
 
     # Before the contract's W warm-up passes: bring the GPU out of its idle state.  A pass of
     # configs[1] is 0.45 ms and the driver's W = 5, K = 20 is 11 ms after seconds of host-side
@@ -508,7 +530,7 @@ def timed_workload(name, args, M, torch, dist, ctx, lanes, rank, world, steps, w
         try:
             while (time.perf_counter() - tp) * 1e3 < args.preheat_ms and preheat["launches"] < 4096:
                 for _ in range(8):
-                    M.demod_batch(ctx, cfg, samples, out=bufs[preheat["launches"] & 1], **kw)
+                    M.demod_batch(ctx, cfg, samples, out=bufs[0], **kw)
                     preheat["launches"] += 1
                 torch.cuda.synchronize()
         except Exception as e:			# noqa: BLE001
@@ -519,17 +541,15 @@ def timed_workload(name, args, M, torch, dist, ctx, lanes, rank, world, steps, w
     # average duration is taken here, from K launches on ONE stream between the preheat and the
     # warm-up passes (untimed by the contract) -- the figure the rocprofv3 summary under profiles/
     # is compared with -- and the K timed passes below are timed by the contract's clock alone.
-    serial_evs = None
-    if pipe > 1:
-        serial_evs = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        try:
-            serial_evs[0].record()		# (torch's current stream, where ctx launches by default)
-            for i in range(steps):
-                M.demod_batch(ctx, cfg, samples, out=bufs[0], **kw)
-            serial_evs[1].record()
-            torch.cuda.synchronize()
-        except Exception as e:			# noqa: BLE001
-            failure[0] = failure[0] or e
+    serial_evs = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    try:
+        serial_evs[0].record()			# (torch's current stream, where ctx launches by default)
+        for i in range(steps):
+            M.demod_batch(ctx, cfg, samples, out=bufs[0], **kw)
+        serial_evs[1].record()
+        torch.cuda.synchronize()
+    except Exception as e:			# noqa: BLE001
+        failure[0] = failure[0] or e
 
     for i in range(warmup):
         step(i)
@@ -540,20 +560,10 @@ def timed_workload(name, args, M, torch, dist, ctx, lanes, rank, world, steps, w
     torch.cuda.synchronize()
     wait_s[0] = 0.0
 
-    # HIP events on the launch stream: ONE pair around the K launches (average launch duration =
-    # elapsed / K, the gaps between launches included), or with --step-events a pair around
-    # every launch (the per-launch spread, at the price of a signal packet between launches:
-    # +7 us per step on configs[1])
-    region = not args.step_events or pipe > 1
-    evs = [serial_evs] if pipe > 1 else [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                                         for _ in range(1 if region else steps)]
+    # (the kernel's own duration: the serial launches above, one event pair around the K of them)
     t0 = time.perf_counter()
-    if region and pipe == 1:
-        evs[0][0].record()
     for i in range(steps):
-        step(i, None if region else evs[i])
-    if region and pipe == 1:
-        evs[0][1].record()
+        step(i)
     drain()
     torch.cuda.synchronize()
     if dist is not None:
@@ -563,11 +573,8 @@ def timed_workload(name, args, M, torch, dist, ctx, lanes, rank, world, steps, w
     # (this rank's own clock stopped after the closing barrier: the same for all; what differs
     # per rank is how long its launches and its waits for the gather took)
     agree(torch, dist, failure[0], "%s: timed loop" % name)
-    del copies[1:]				# (the lanes' copies of the batch: nothing below reads them)
 
-    kernel_ms = [a.elapsed_time(b) for a, b in evs]
-    if region:
-        kernel_ms = [kernel_ms[0] / max(1, steps)] * steps
+    kernel_ms = [serial_evs[0].elapsed_time(serial_evs[1]) / max(1, steps)] * steps
     total_samples = total_samples_local
     per_rank = None
     if dist is not None:
@@ -587,9 +594,17 @@ def timed_workload(name, args, M, torch, dist, ctx, lanes, rank, world, steps, w
                     "gather_wait_ms_per_step": [float(a[2]) for a in allr],
                     "gather_bytes_per_peer_per_step": gatherer.bytes_per_peer(nstreams)}
 
-    last = (steps - 1) % nbuf if steps else 0
-    res = M.results_to_host(bufs[last])
+    # every output set the timed passes wrote against the serial launches' set (bufs[0])
+    res = M.results_to_host(bufs[0])
     gpu_bytes, gpu_nbytes = res["bytes"], res["nbytes"]
+    sets_equal = 0
+    for b in range(nbuf):
+        r = M.results_to_host(pipeline.result(b))
+        same = np.array_equal(r["nbytes"], gpu_nbytes) and np.array_equal(r["nframes"], res["nframes"])
+        if same:
+            mask = np.arange(gpu_bytes.shape[1])[None, :] < gpu_nbytes[:, None].astype(np.int64)
+            same = np.array_equal(r["bytes"][mask], gpu_bytes[mask])
+        sets_equal += bool(same)
 
     # ---- the checker leg (outside every timed region): the WHOLE shard against the oracle,
     # frame for frame -- bits, starts, flags, confidence and amplitude bit patterns, episodes,
@@ -665,6 +680,14 @@ def timed_workload(name, args, M, torch, dist, ctx, lanes, rank, world, steps, w
                     peers_judged += 1
                     peers_ok += bool(v)
 
+    gather_self_ok = None
+    if args.gather_self and world == 1:
+        # what the last gather delivered (to this rank, from itself) against the set it was sent from
+        rb, rn = gatherer.received(0)
+        last = M.results_to_host(pipeline.result((pipeline.next_ticket() - 1) % nbuf))
+        gather_self_ok = bool(np.array_equal(rn.cpu().numpy(), last["nbytes"])
+                              and np.array_equal(rb.cpu().numpy(), last["bytes"][:, :rb.shape[1]]))
+
     line = None
     if rank == 0:
         value = total_samples * steps / dt
@@ -689,18 +712,21 @@ def timed_workload(name, args, M, torch, dist, ctx, lanes, rank, world, steps, w
                          "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": hbm_traffic(name),
                          "kernel": launch["kernel"], "launch": launch,
                          "kernel_ms_avg": kavg * 1e3, "kernel_ms_min": float(np.min(kernel_ms)),
-                         "events": ("one pair around K launches on one stream, between the preheat and the warm-up passes"
-                                    if pipe > 1 else "one pair around the K launches" if not args.step_events
-                                    else "a pair per launch"),
+                         "events": "one pair around K launches on one stream, between the preheat and the warm-up passes",
                          "algorithmic_bytes_per_launch": total_samples_local * 4.0},
             "payload_roundtrip_ok_streams": "%d/%d" % (ok_streams, judged),
             "device": ctx.device_name,
-            "pipeline": {"passes_in_flight": pipe, "streams": pipe,
-                         "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
+            # (one batch at a time per GPU: the job's samples over the slowest rank's kernel time)
+            "value_serial": total_samples / (max(per_rank["kernel_ms_avg"]) * 1e-3 if per_rank else kavg),
+            "cold_ms_per_step": cold_ms,
+            "pipeline": {"passes_in_flight": pipe, "asked_for": pipeline.depth_requested,
+                         "hw_queues": pipeline.hw_queues, "through": "mifsk_pipeline_* (C ABI)",
                          "ms_per_pass": dt / steps * 1e3,
                          "hbm_frac_of_the_timed_passes": total_samples_local * 4.0 * steps / dt / HBM_PEAK,
-                         "note": "pass i runs on stream i mod P (own context, own copy of the batch, own outputs): it fills the CUs "
-                                 "the late streams of pass i - 1 leave idle; roofline.* is the kernel launched "
+                         "output_sets_equal_to_serial_launch": "%d/%d" % (sets_equal, nbuf),
+                         "note": "pass i runs on lane i mod P of the library's pipeline (a context, a HIP stream "
+                                 "and an output set each; one resident batch): it fills the CUs the late streams "
+                                 "of pass i - 1 leave idle; roofline.* and value_serial are the kernel launched "
                                  "serially on one stream"},
             "preheat": {"untimed_launches_before_warmup": preheat["launches"], "ms": preheat["ms"],
                         "why": "the first launches after host-side set-up run at idle clocks"},
@@ -713,10 +739,17 @@ def timed_workload(name, args, M, torch, dist, ctx, lanes, rank, world, steps, w
             line["oracle"] = oracle
         if world > 1:
             line["payload_roundtrip_ok_streams_gathered_from_peers"] = "%d/%d" % (peers_ok, peers_judged)
+        if gather_self_ok is not None:
+            line["gather_self_ok"] = gather_self_ok
+        if per_rank is not None:
             line["per_rank"] = per_rank
+            line["ranks"] = {"world_size": int(dist.get_world_size()), "backend": str(dist.get_backend())}
         if world == 1 and cpu_leg:
-            # a bounded sample of the same batch on the host cores
+            # a bounded sample of the same batch on the host cores ("ref": the reference program
+            # alone on 64 streams -- what the default run does for the workloads after the first)
             k = nstreams if name == "1200" else {"rtty": 256, "12000": 1024, "same": 512, "1200noise": 256}[name]
+            if cpu_leg == "ref":
+                k = 64
             k = min(k, nstreams)
             hs = samples[:k].cpu().numpy()
             hl = np.full(k, nsamp, np.int64) if lens is None else lens[:k].cpu().numpy().astype(np.int64)
@@ -730,15 +763,46 @@ def timed_workload(name, args, M, torch, dist, ctx, lanes, rank, world, steps, w
                                       r2["episodes"][i, :min(64, int(r2["nepisodes"][i]))], quiet=True)[0]
                         for i in range(k)]
             line.update(cpu_baselines(name, mode, int(cfg.sample_rate), hs, hl, gpu_bytes, gpu_nbytes,
-                                      gpu_text))
+                                      gpu_text, budget_s=6.0 if cpu_leg == "ref" else 18.0,
+                                      port=cpu_leg != "ref"))
         if world == 1 and name == "1200" and not args.no_h2d:
             line["h2d_inclusive"] = h2d_inclusive(M, torch, ctx, cfg, samples, nsamp, frames_cap, gpu_bytes,
                                                   gpu_nbytes)
-        if world == 1 and name == "1200" and cpu_leg:
+        if world == 1 and name == "1200" and cpu_leg is True:
             line["legacy_dropin"] = legacy_dropin(samples, nsamp, int(cfg.sample_rate))
+        if world == 1 and name == "1200" and args.config is None and failure[0] is None:
+            line["small_batch"] = small_batch(M, torch, ctx, cfg, samples, nsamp, steps, kw)
     del samples, bufs
     torch.cuda.empty_cache()
     return line
+
+
+def small_batch(M, torch, ctx, cfg, samples, nsamp, steps, kw):
+    """configs[1] at 64 / 256 / 512 streams, K launches serially on one stream after the preheat:
+    below one workgroup per CU (256 streams) the launch lasts as long as ONE stream's serial chain
+    whatever the batch size -- the regime a small job is in (no time parallelism inside a stream:
+    DESIGN.md section 8)."""
+    out = {"unit": "ms per launch (serial, events around K launches)"}
+    for n in (64, 256, 512):
+        if n > samples.shape[0]:
+            continue
+        try:
+            sub = samples[:n]
+            buf = M.demod_batch(ctx, cfg, sub, **kw)
+            for _ in range(3):
+                M.demod_batch(ctx, cfg, sub, out=buf, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(steps):
+                M.demod_batch(ctx, cfg, sub, out=buf, **kw)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / max(1, steps)
+            out[str(n)] = {"kernel_ms_avg": ms, "samples_per_s": n * nsamp / (ms * 1e-3),
+                           "roofline_frac": n * nsamp * 4.0 / (ms * 1e-3) / HBM_PEAK}
+        except Exception as e:				# noqa: BLE001 -- a diagnostic leg must not kill the line
+            out[str(n)] = {"error": repr(e)}
+    return out
 
 
 def h2d_inclusive(M, torch, ctx, cfg, samples, nsamp, frames_cap, gpu_bytes, gpu_nbytes):
@@ -855,8 +919,9 @@ def main():
                          "0 = the workload's own default, 3 or 4)")
     ap.add_argument("--preheat-ms", type=float, default=300.0,
                     help="untimed kernel launches before the W warm-up passes (0 = none)")
-    ap.add_argument("--step-events", action="store_true",
-                    help="an event pair around every launch instead of one around the K launches")
+    ap.add_argument("--gather-self", action="store_true",
+                    help="N = 1 only: run the N > 1 step structure anyway -- process group on the nccl "
+                         "backend, the gather of every pass as a send to this rank itself on the lane's stream")
     ap.add_argument("--engine", default=None, choices=["wave", "workgroup"],
                     help="force a receive-loop engine (default: the library chooses)")
     args = ap.parse_args()
@@ -868,6 +933,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, "WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus)
+
+    # ONE JSON line on stdout and nothing else: libraries below print there too (RCCL writes a
+    # version banner through C stdio, flushed when the process exits -- after the line).  The line
+    # goes to a private copy of stdout; file descriptor 1 itself is pointed at stderr, on every rank.
+    sys.stdout.flush()
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(line_fd, (json.dumps(obj) + "\n").encode())
 
     if os.environ.get("MIFSK_BENCH_DRYRUN"):
         # the launch path without a GPU (tests/test_distributed_cpu.py): rendezvous over gloo,
@@ -891,10 +966,10 @@ def main():
         else:
             table = [torch.tensor([lo, hi], dtype=torch.int64)]
         if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": world, "total_streams": int(t.item()),
-                              "scaling": args.scaling, "config": args.config or "1200",
-                              "shards": [[int(a[0]), int(a[1])] for a in table],
-                              "launcher": os.environ.get("TORCHELASTIC_RUN_ID", "") != "" or world == 1}))
+            emit({"dry_run": True, "n_gpus": world, "total_streams": int(t.item()),
+                  "scaling": args.scaling, "config": args.config or "1200",
+                  "shards": [[int(a[0]), int(a[1])] for a in table],
+                  "launcher": os.environ.get("TORCHELASTIC_RUN_ID", "") != "" or world == 1})
         if world > 1:
             dist.destroy_process_group()
         return
@@ -904,9 +979,10 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.gather_self:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
     ctx = M.Context(local_rank)
@@ -917,12 +993,13 @@ def main():
     if args.config is None and not args.no_extra:
         # the other BASELINE entries at their stated per-GPU sizes, the same K and W (with passes in
         # flight a handful of passes would mostly measure the pipeline filling and draining), device
-        # generator, no CPU leg: driver-visible kernel time and roofline fraction per entry
+        # generator; CPU leg: the reference program on 64 streams of each (its stdout against the
+        # GPU's): driver-visible kernel time, roofline fraction and reference comparison per entry
         extra = {}
         for other in ("1200noise", "12000", "same", "rtty"):	# (shortest kernels first, the 12 ms one last)
             try:
                 sub = run_workload(other, args, M, torch, dist, ctx, rank, world,
-                                   args.steps, args.warmup, cpu_leg=False,
+                                   args.steps, args.warmup, cpu_leg=False if args.no_cpu else "ref",
                                    oracle_leg=not args.no_cpu)
             except RankFailed as e:
                 # (raised on EVERY rank by agree(): nobody is left inside a collective)
@@ -936,17 +1013,23 @@ def main():
                 extra[other] = {
                     "workload": sub["config"]["workload"], "value": sub["value"], "unit": sub["unit"],
                     "steps": sub["steps"], "ms_per_step": sub["ms_per_step"],
+                    "value_serial": sub["value_serial"], "cold_ms_per_step": sub["cold_ms_per_step"],
                     "kernel": rf["kernel"], "kernel_ms_avg": rf["kernel_ms_avg"],
                     "algorithmic_bytes_per_launch": rf["algorithmic_bytes_per_launch"],
                     "roofline": {"bound": "hbm", "achieved": rf["achieved"], "peak": rf["peak"],
                                  "unit": rf["unit"], "frac": rf["frac"], "traffic": rf["traffic"]},
                     "launch": rf["launch"],
-                    "pipeline": {k: sub["pipeline"][k] for k in ("passes_in_flight", "ms_per_pass",
-                                                                 "hbm_frac_of_the_timed_passes")},
+                    "pipeline": {k: sub["pipeline"][k] for k in ("passes_in_flight", "asked_for", "hw_queues", "ms_per_pass",
+                                                                 "hbm_frac_of_the_timed_passes",
+                                                                 "output_sets_equal_to_serial_launch")},
                     "payload_roundtrip_ok_streams": sub["payload_roundtrip_ok_streams"],
                     "oracle_mismatching_streams": sub.get("oracle_mismatching_streams"),
                     "oracle": sub.get("oracle"),
                 }
+                if "cpu_baseline" in sub:
+                    # the reference PROGRAM on a sample of this workload too (64 streams)
+                    extra[other]["cpu_baseline"] = sub["cpu_baseline"]
+                    extra[other]["reference_mismatching_streams"] = sub["cpu_baseline"].get("mismatching_streams")
                 if "per_rank" in sub:
                     extra[other]["per_rank"] = sub["per_rank"]
                 if "payload_by_condition" in sub:
@@ -957,7 +1040,7 @@ def main():
         if rank == 0:
             line["configs"] = extra
     if rank == 0:
-        print(json.dumps(line))
+        emit(line)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

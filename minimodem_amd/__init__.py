@@ -549,11 +549,16 @@ class ByteGatherer:
     longest) -- only those are shipped, from a narrow staging copy made on the
     caller's stream (`slots` of them, used in turn like the caller's buffers).
     rows: streams per rank when the shards differ in size (default: all ranks
-    hold as many as this one)."""
+    hold as many as this one).
+    loopback (world size 1 only): the one rank sends to ITSELF and receives it in the same
+    group -- the whole transport (narrow staging copy, grouped isend/irecv, receive sets) on one
+    GPU, which is how the N > 1 step structure is exercised where only one GPU is there;
+    received(0) is then what it sent itself."""
 
-    def __init__(self, dist, rank, world, cols=None, rows=None, slots=2):
+    def __init__(self, dist, rank, world, cols=None, rows=None, slots=2, loopback=False):
         self.dist, self.rank, self.world = dist, rank, world
         self.cols, self.rows = cols, rows
+        self.loopback = bool(loopback) and world == 1
         self.slots = max(2, int(slots))
         self._rx = [None] * self.slots
         self._tx = [None] * self.slots
@@ -566,10 +571,25 @@ class ByteGatherer:
 
     def start(self, local_bytes, local_nbytes):
         dist = self.dist
-        if self.world == 1:
+        if self.world == 1 and not self.loopback:
             return []
         cols = local_bytes.shape[1] if self.cols is None else min(int(self.cols), local_bytes.shape[1])
         self.cols = cols
+        if self.loopback:
+            torch = _torch()
+            slot = self._k % self.slots
+            self._k += 1
+            self._last = slot
+            if self._rx[slot] is None:
+                self._rx[slot] = [(torch.empty((local_bytes.shape[0], cols), dtype=local_bytes.dtype, device=local_bytes.device),
+                                   torch.empty_like(local_nbytes))]
+                self._tx[slot] = torch.empty((local_bytes.shape[0], cols), dtype=local_bytes.dtype,
+                                             device=local_bytes.device)
+            self._tx[slot].copy_(local_bytes[:, :cols])
+            rb, rn = self._rx[slot][0]
+            ops = [dist.P2POp(dist.irecv, rb, 0), dist.P2POp(dist.irecv, rn, 0),
+                   dist.P2POp(dist.isend, self._tx[slot], 0), dist.P2POp(dist.isend, local_nbytes, 0)]
+            return dist.batch_isend_irecv(ops)
         if self.rank == 0:
             slot = self._k % self.slots
             self._k += 1
@@ -599,7 +619,7 @@ class ByteGatherer:
         return dist.batch_isend_irecv(ops)
 
     def received(self, r, slot=None):
-        return self._rx[self._last if slot is None else slot % self.slots][r - 1]
+        return self._rx[self._last if slot is None else slot % self.slots][0 if self.loopback else r - 1]
 
 
 DECODERS = {"ascii8": 0, "baudot": 1, "binary": 2, "callerid": 3, "uic-ground": 4, "uic-train": 5}

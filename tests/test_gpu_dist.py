@@ -69,3 +69,34 @@ def test_bench_line_for_every_config_small():
         assert judged > 0 and ok >= judged * 0.9, line["payload_roundtrip_ok_streams"]
         assert line["cpu_port"]["mismatching_streams"] == 0
         assert line["cpu_baseline"]["mismatching_streams"] == 0
+
+
+def test_bench_step_structure_of_n_gt_1_on_one_gpu_with_the_gather_sent_to_itself():
+    """What the driver's scaling run executes at N > 1 -- process group on the `nccl` backend with a
+    device id, the library's pipeline, the gather of every pass queued on its lane's stream with
+    several in flight, agree(), the per-rank reductions -- at world size 1 with the gather forced
+    on as a send of every pass's bytes to this rank itself (bench.py --gather-self).  The line
+    must carry per_rank, RCCL's own rank count, and what came back must be what was sent."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29519", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for cfg, streams in (("1200", 512), ("12000", 1024)):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", cfg, "--streams", str(streams),
+                            "--steps", "8", "--warmup", "2", "--gather-self", "--no-cpu", "--no-h2d",
+                            "--preheat-ms", "50"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           timeout=600, cwd=root, env=env)
+        assert r.returncode == 0, r.stderr.decode()[-3000:]
+        line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+        assert line["n_gpus"] == 1 and line["gather_self_ok"] is True
+        assert line["ranks"] == {"world_size": 1, "backend": "nccl"}
+        pr = line["per_rank"]
+        assert len(pr["kernel_ms_avg"]) == 1 and pr["kernel_ms_avg"][0] > 0
+        assert pr["gather_bytes_per_peer_per_step"] > 0
+        assert line["pipeline"]["passes_in_flight"] >= 1
+        sets = line["pipeline"]["output_sets_equal_to_serial_launch"].split("/")
+        assert sets[0] == sets[1]
+        ok, judged = (int(v) for v in line["payload_roundtrip_ok_streams"].split("/"))
+        assert ok == judged > 0
+        assert line["value_serial"] > 0 and line["cold_ms_per_step"] > 0
