@@ -110,21 +110,23 @@ def condition_label(kind, v):
 
 def apply_conditions(name, torch, samples, lens, lo, rank, amplitude):
     """AWGN at the condition's SNR (signal power amplitude^2 / 2, seeded per rank) or the
-    reference's --Xrxnoise DC term, condition (lo + i) % len(conditions) on row i; the rows'
-    zero padding beyond their length stays zero."""
+    reference's --Xrxnoise DC term, condition (lo + i) % len(conditions) on row i, over each row's
+    own length (`lens`; None: the whole row) -- the zero padding beyond it stays zero."""
     conds = CONDITIONS[name]
     nc = len(conds)
     p_sig = amplitude ** 2 / 2
     g = torch.Generator(device="cuda")
     g.manual_seed(1000 + rank)
+    cols = torch.arange(samples.shape[1], device="cuda")[None, :]
     for k, (kind, v) in enumerate(conds):
         first = (k - lo) % nc
         rows = samples[first::nc]
+        inside = 1.0 if lens is None else (cols < lens[first::nc][:, None]).to(torch.float32)
         if kind == "snr_db" and v is not None:
             sigma = float(np.sqrt(p_sig / 10 ** (v / 10)))
-            rows += torch.randn(rows.shape, generator=g, device="cuda", dtype=torch.float32) * sigma
+            rows += torch.randn(rows.shape, generator=g, device="cuda", dtype=torch.float32) * sigma * inside
         elif kind == "dc":
-            rows -= np.float32(v)
+            rows -= np.float32(v) * inside
 
 
 def make_stream(M, cfg, gid):

@@ -293,7 +293,12 @@ typedef struct mifsk_demod_io {
  * shared-segment scans and of --auto-carrier) */
 #define MIFSK_CNT_CONF_FALLBACKS 24	/* confidence passes that took the divisions proper (a
 					   zero / non-finite class mean or a subnormal quotient
-					   somewhere in the wave: frame_confidence_fixed)          */
+					   somewhere in the wave: frame_confidence_fixed).  A LOWER
+					   bound: lane 0 does the counting, and a pass whose lane 0
+					   had left already (its candidate's required bits mismatch)
+					   is not counted -- counting it through a ballot moved the
+					   register allocation of the loop kernels and cost 1-2 %
+					   (profiles/r06_history.md)                               */
 
 /* Asynchronous on `stream`: the outputs are complete when `stream` reaches the point
  * behind the call.  (A large wavefront-engine batch is run as several launches on

@@ -193,6 +193,14 @@ def demod_batch(ctx, cfg, samples, nsamples=None, want=("bytes", "episodes"),
                 out["episodes"] = torch.zeros((nstreams, episodes_cap, EPISODE_DTYPE.itemsize),
                                               dtype=torch.uint8, device=dev)
                 out["nepisodes"] = torch.zeros(nstreams, dtype=torch.int32, device=dev)
+        if stream is not None:
+            # The tensors belong to `stream` in torch's caching allocator.  Whoever reads them on
+            # another stream must order that read behind `stream` (an event, wait_stream); marking
+            # them used on the current stream as well keeps the allocator from handing a dropped
+            # tensor's block back out -- and its zero-fill onto `stream` -- under such a reader.
+            cur = torch.cuda.current_stream()
+            for t in out.values():
+                t.record_stream(cur)
 
     def ptr(name):
         t = out.get(name)
@@ -964,6 +972,10 @@ class SlabSession:
         for i, x in enumerate(new):
             if x is not None and len(x):
                 self.tail[i] = np.concatenate([self.tail[i], np.asarray(x, np.float32)])
+        if stream is not None:
+            # (state and ring were made -- and on the first feed zero-filled -- on the stream that
+            # was current then: this stream starts behind it)
+            stream.wait_stream(torch.cuda.current_stream())
         width = (max([len(t) for t in self.tail] + [4]) + 3) & ~3
         host = np.zeros((self.n, width), np.float32)
         lens = np.zeros(self.n, np.int32)

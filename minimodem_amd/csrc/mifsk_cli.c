@@ -101,7 +101,27 @@ static int write_wav( const char *path, const float *x, size_t n, unsigned rate,
  * zero / negative = not given, as the options leave minimodem's own variables).  Returns the
  * process's exit status.  Also what integration/minimodem-rx-batch.patch calls from inside the
  * reference's own main() (there with one file: the reference takes one --file). */
-enum { MIFSK_CLI_FLAT = 1, MIFSK_CLI_QUIET = 2, MIFSK_CLI_PRINT_FILTER = 4, MIFSK_CLI_STATS = 8 };
+enum { MIFSK_CLI_FLAT = 1, MIFSK_CLI_QUIET = 2, MIFSK_CLI_PRINT_FILTER = 4, MIFSK_CLI_STATS = 8,
+       /* a file that is not a mono PCM16 / float32 WAV is NOT an error of this function: it
+	* returns MIFSK_CLI_NOT_HANDLED before anything is printed or any device is touched, and the
+	* caller -- the reference's main(), which reads FLAC, AIFF, AU, 24-bit PCM ... through
+	* libsndfile -- goes on into its own receive loop */
+       MIFSK_CLI_FALLTHROUGH = 16 };
+#define MIFSK_CLI_NOT_HANDLED	(-2)
+
+/* 0: `path` starts with a RIFF/WAVE header the batch path takes; otherwise mifsk_wav_parse's
+ * verdict (-EINVAL / -ENOTSUP) or -errno */
+static int probe_wav( const char *path )
+{
+    unsigned char head[4096];
+    FILE *f = fopen(path, "rb");
+    if ( !f )
+	return -errno;
+    const size_t n = fread(head, 1, sizeof(head), f);
+    fclose(f);
+    mifsk_wav_info info;
+    return mifsk_wav_parse(head, n, &info);
+}
 
 int mifsk_cli_rx_files( const mifsk_modem_args *a, const char *const *files, int nfiles, float rxnoise,
 	unsigned flags )
@@ -111,6 +131,13 @@ int mifsk_cli_rx_files( const mifsk_modem_args *a, const char *const *files, int
      * the device, demodulated chunk by chunk: mifsk_demod_files) */
     const int flat = ( flags & MIFSK_CLI_FLAT ) != 0, quiet = ( flags & MIFSK_CLI_QUIET ) != 0;
     const int print_filter = ( flags & MIFSK_CLI_PRINT_FILTER ) != 0, stats = ( flags & MIFSK_CLI_STATS ) != 0;
+    if ( flags & MIFSK_CLI_FALLTHROUGH ) {
+	for ( int i = 0; i < nfiles; i++ ) {
+	    const int v = probe_wav(files[i]);
+	    if ( v == -EINVAL || v == -ENOTSUP )
+		return MIFSK_CLI_NOT_HANDLED;
+	}
+    }
     mifsk_ctx *ctx = NULL;
     int rc = mifsk_ctx_create(&ctx, -1);
     if ( rc ) {
@@ -122,6 +149,7 @@ int mifsk_cli_rx_files( const mifsk_modem_args *a, const char *const *files, int
 			   flat ? 0u : MIFSK_IO_RING_EXACT, &res);
     if ( rc ) {
 	fprintf(stderr, "E: mifsk_demod_files failed (%d)\n", rc);
+	mifsk_ctx_destroy(ctx);
 	return 1;
     }
     const unsigned tflags = ( print_filter ? MIFSK_TEXT_PRINT_FILTER : 0 ) | ( quiet ? MIFSK_TEXT_QUIET : 0 );
@@ -147,6 +175,13 @@ int mifsk_cli_rx_files( const mifsk_modem_args *a, const char *const *files, int
 	const size_t out_cap = 64 + 320 * (size_t)( fr->nframes ? fr->nframes : 1 );
 	const size_t err_cap = 256 + 512 * (size_t)( fr->nepisodes ? fr->nepisodes : 1 );
 	char *out = malloc(out_cap), *err = malloc(err_cap);
+	if ( !out || !err ) {
+	    fprintf(stderr, "E: %s: out of memory\n", files[i]);
+	    free(out);
+	    free(err);
+	    failed = 1;
+	    continue;
+	}
 	rc = mifsk_stream_text(fr->cfg, fr->bits, fr->nframes, fr->episodes, fr->nepisodes, tflags,
 			       out, out_cap, &out_len, err, err_cap, &err_len);
 	if ( rc && rc != -ENOSPC ) {

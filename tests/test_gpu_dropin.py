@@ -76,3 +76,22 @@ def test_reference_main_with_the_rx_batch_patch(name, tmp_path):
     assert r.stdout == g["stdout"]
     lines = [l for l in r.stderr.decode().splitlines() if l.startswith("### NOCARRIER")]
     assert lines == g["nocarrier"]
+
+
+@pytest.mark.skipif(not os.path.exists(RXBATCH) or not O.have_ref(), reason="oracle/_ref not built")
+def test_rx_batch_patch_leaves_files_it_does_not_read_to_the_reference_loop(tmp_path):
+    """The batch entry reads mono PCM16 / float32 WAV; the reference opens whatever libsndfile
+    opens (FLAC, AIFF, AU, 24-bit PCM ...: /root/reference/src/simpleaudio-sndfile.c:113-160).
+    For anything else the patched main() must behave as if the patch were not there: the file goes
+    to the reference's own receive loop -- here, with the WAV-only libsndfile shim under it, to the
+    reference's own "cannot open" failure, word for word what the unpatched program says -- and
+    not to an error message of the batch path's."""
+    au = tmp_path / "in.au"
+    au.write_bytes(b".snd" + struct.pack(">IIIII", 24, 8000, 3, 48000, 1) + bytes(8000))
+    outs = []
+    for exe in (O.MINIMODEM_REF, RXBATCH):
+        r = subprocess.run([exe, "--rx", "--file", str(au), "1200"], stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, timeout=120)
+        outs.append((r.returncode, r.stdout, r.stderr))
+    assert outs[0] == outs[1], outs
+    assert b"not a mono PCM16" not in outs[1][2]
