@@ -29,6 +29,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "mifsk.h"
 
@@ -109,6 +110,13 @@ enum { MIFSK_CLI_FLAT = 1, MIFSK_CLI_QUIET = 2, MIFSK_CLI_PRINT_FILTER = 4, MIFS
        MIFSK_CLI_FALLTHROUGH = 16 };
 #define MIFSK_CLI_NOT_HANDLED	(-2)
 
+static double cli_now( void )
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
 /* 0: `path` starts with a RIFF/WAVE header the batch path takes; otherwise mifsk_wav_parse's
  * verdict (-EINVAL / -ENOTSUP) or -errno */
 static int probe_wav( const char *path )
@@ -138,15 +146,20 @@ int mifsk_cli_rx_files( const mifsk_modem_args *a, const char *const *files, int
 		return MIFSK_CLI_NOT_HANDLED;
 	}
     }
+    /* MIFSK_CLI_TIMING=1: where a call's wall time goes, on stderr */
+    const int timing = getenv("MIFSK_CLI_TIMING") != NULL;
+    const double t_0 = cli_now();
     mifsk_ctx *ctx = NULL;
     int rc = mifsk_ctx_create(&ctx, -1);
     if ( rc ) {
 	fprintf(stderr, "E: no MI355X available (%d); this program has no CPU receive path\n", rc);
 	return 1;
     }
+    const double t_ctx = cli_now();
     mifsk_files *res = NULL;
     rc = mifsk_demod_files(ctx, a, files, nfiles, rxnoise,
 			   flat ? 0u : MIFSK_IO_RING_EXACT, &res);
+    const double t_demod = cli_now();
     if ( rc ) {
 	fprintf(stderr, "E: mifsk_demod_files failed (%d)\n", rc);
 	mifsk_ctx_destroy(ctx);
@@ -200,8 +213,13 @@ int mifsk_cli_rx_files( const mifsk_modem_args *a, const char *const *files, int
 		st->streams, st->chunks, st->bytes_h2d / 1e6, st->seconds_total,
 		st->seconds_total > 0 ? st->bytes_h2d / st->seconds_total / 1e9 : 0.0, st->seconds_staging);
     }
+    const double t_text = cli_now();
     mifsk_files_free(res);
     mifsk_ctx_destroy(ctx);
+    if ( timing )
+	fprintf(stderr, "### TIMING context (HIP start, device) %.1f ms, mifsk_demod_files %.1f ms, text %.1f ms, "
+			"teardown %.1f ms\n", 1e3 * ( t_ctx - t_0 ), 1e3 * ( t_demod - t_ctx ),
+		1e3 * ( t_text - t_demod ), 1e3 * ( cli_now() - t_text ));
     return failed;
 }
 

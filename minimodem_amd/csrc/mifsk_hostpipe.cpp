@@ -92,12 +92,17 @@ int host_work_get( mifsk_ctx *ctx, HostWork **out )
     return 0;
 }
 
-int host_work_init( HostWork *w )
+// `overlapped`: the job has more than one chunk, i.e. something to overlap: the copy streams and
+// the events that order the three are made then.  A job of one chunk -- a file, a few files: the
+// reference's own use -- runs on s_comp alone (a stream costs ~10 ms to make: a third of what
+// such a call spent inside the library).
+int host_work_init( HostWork *w, bool overlapped )
 {
-    if ( w->ready )
+    if ( w->ready || !overlapped )
 	return 0;
+    if ( !w->s_comp )
+	HIP_OK(hipStreamCreateWithFlags(&w->s_comp, hipStreamNonBlocking));
     HIP_OK(hipStreamCreateWithFlags(&w->s_in, hipStreamNonBlocking));
-    HIP_OK(hipStreamCreateWithFlags(&w->s_comp, hipStreamNonBlocking));
     HIP_OK(hipStreamCreateWithFlags(&w->s_out, hipStreamNonBlocking));
     for ( int i = 0; i < 2; i++ ) {
 	HIP_OK(hipEventCreateWithFlags(&w->ev_in[i], hipEventDisableTiming));
@@ -291,10 +296,9 @@ int run_job( mifsk_ctx *ctx, Job &job )
     if ( rc )
 	return rc;
     std::lock_guard<std::mutex> g(w->lock);
-    rc = host_work_init(w);
-    if ( rc )
-	return rc;
-    const double t_begin = now_s();
+    // MIFSK_CLI_TIMING=1: the phases of a job on stderr (what a batch of ONE pays: INTEGRATION.md 1b)
+    const bool timing = std::getenv("MIFSK_CLI_TIMING") != nullptr;
+    const double t_enter = now_s();
     const size_t esz = job.s16 ? 2 : 4;
 
     // chunks of whole streams, ~kChunkBytes of input each
@@ -322,6 +326,14 @@ int run_job( mifsk_ctx *ctx, Job &job )
     }
     for ( size_t i = 1; i < nrows; i++ )
 	uniform_n = uniform_n && job.rows[i].n == job.rows[0].n;
+    const bool single = chunks.size() == 1;
+    rc = host_work_init(w, !single);
+    if ( rc )
+	return rc;
+    const double t_begin = now_s();
+    // (one chunk: everything in order on the null stream, which the runtime has anyway)
+    const hipStream_t st_comp = single ? nullptr : w->s_comp;
+    const hipStream_t st_in = single ? st_comp : w->s_in, st_out = single ? st_comp : w->s_out;
 
     // page-locked source rows are copied from where they are
     const bool direct = job.rows[0].mem && job.src_pitch && is_pinned(job.rows[0].mem)
@@ -349,6 +361,7 @@ int run_job( mifsk_ctx *ctx, Job &job )
 	if ( ho.d_counters && dev_alloc(&s.d_cnt, max_rows * MIFSK_NCOUNTERS) ) return -ENOMEM;
     }
 
+    const double t_alloc = now_s();
     const unsigned nthreads = staging_threads();
     // (a test hook like every other knob: honoured only with MIFSK_EXPERIMENT set, so that a stray
     // variable cannot turn production reads into rows of zeros)
@@ -362,11 +375,12 @@ int run_job( mifsk_ctx *ctx, Job &job )
 	const Chunk &c = chunks[ci];
 	const Slot &s = sg.s[ci & 1];
 	const size_t r = c.hi - c.lo;
-	HIP_OK(hipStreamWaitEvent(w->s_out, w->ev_comp[ci & 1], 0));
+	if ( !single )
+	    HIP_OK(hipStreamWaitEvent(st_out, w->ev_comp[ci & 1], 0));
 #define MIFSK_OUT(HOSTP, DEVP, PER_ROW)										\
 	if ( HOSTP ) {												\
 	    const size_t nb = r * (PER_ROW) * sizeof(*(HOSTP));							\
-	    HIP_OK(hipMemcpyAsync((HOSTP) + c.lo * (PER_ROW), DEVP, nb, hipMemcpyDeviceToHost, w->s_out));	\
+	    HIP_OK(hipMemcpyAsync((HOSTP) + c.lo * (PER_ROW), DEVP, nb, hipMemcpyDeviceToHost, st_out));	\
 	    bytes_out += nb;											\
 	}
 	MIFSK_OUT(ho.d_bytes, s.d_bytes, fc)
@@ -382,7 +396,8 @@ int run_job( mifsk_ctx *ctx, Job &job )
 	    MIFSK_OUT(ho.d_carrier_band, s.d_band, 1)
 	}
 #undef MIFSK_OUT
-	HIP_OK(hipEventRecord(w->ev_out[ci & 1], w->s_out));
+	if ( !single )
+	    HIP_OK(hipEventRecord(w->ev_out[ci & 1], st_out));
 	return 0;
     };
 
@@ -438,22 +453,24 @@ int run_job( mifsk_ctx *ctx, Job &job )
 	    src_pitch_bytes = c.stride * esz;
 	}
 	if ( src_pitch_bytes == c.stride * esz )	// rows back to back on both sides: one linear copy
-	    HIP_OK(hipMemcpyAsync(s.d_in, src, width * r, hipMemcpyHostToDevice, w->s_in));
+	    HIP_OK(hipMemcpyAsync(s.d_in, src, width * r, hipMemcpyHostToDevice, st_in));
 	else
 	    HIP_OK(hipMemcpy2DAsync(s.d_in, c.stride * esz, src, src_pitch_bytes, width, r,
-				    hipMemcpyHostToDevice, w->s_in));
-	HIP_OK(hipMemcpyAsync(s.d_n, w->pin_n[sl], r * sizeof(uint32_t), hipMemcpyHostToDevice, w->s_in));
-	HIP_OK(hipEventRecord(w->ev_in[sl], w->s_in));
+				    hipMemcpyHostToDevice, st_in));
+	HIP_OK(hipMemcpyAsync(s.d_n, w->pin_n[sl], r * sizeof(uint32_t), hipMemcpyHostToDevice, st_in));
 	bytes_in += width * r;
 	// ---- convert + receive loop
-	HIP_OK(hipStreamWaitEvent(w->s_comp, w->ev_in[sl], 0));
+	if ( !single ) {
+	    HIP_OK(hipEventRecord(w->ev_in[sl], st_in));
+	    HIP_OK(hipStreamWaitEvent(st_comp, w->ev_in[sl], 0));
+	}
 	const float *d_x = (const float *)s.d_in;
 	if ( job.s16 ) {
 	    rc = mifsk_ingest_s16(ctx, (const int16_t *)s.d_in, c.stride, s.d_x, c.stride, s.d_n, 0,
-				  (int)r, job.rxnoise, w->s_comp);
+				  (int)r, job.rxnoise, st_comp);
 	    d_x = s.d_x;
 	} else if ( job.rxnoise != 0.0f ) {
-	    rc = mifsk_ingest_rxnoise_f32(ctx, (float *)s.d_in, c.stride, s.d_n, 0, (int)r, job.rxnoise, w->s_comp);
+	    rc = mifsk_ingest_rxnoise_f32(ctx, (float *)s.d_in, c.stride, s.d_n, 0, (int)r, job.rxnoise, st_comp);
 	}
 	if ( rc )
 	    return rc;
@@ -470,10 +487,11 @@ int run_job( mifsk_ctx *ctx, Job &job )
 	io.d_episodes = s.d_eps;	io.d_nepisodes = s.d_neps;	io.episodes_cap = ec;
 	io.d_status = s.d_status;	io.d_counters = s.d_cnt;	io.d_carrier_band = s.d_band;
 	io.flags = job.flags;
-	rc = mifsk_demod_batch(ctx, job.cfg, &io, w->s_comp);
+	rc = mifsk_demod_batch(ctx, job.cfg, &io, st_comp);
 	if ( rc )
 	    return rc;
-	HIP_OK(hipEventRecord(w->ev_comp[sl], w->s_comp));
+	if ( !single )
+	    HIP_OK(hipEventRecord(w->ev_comp[sl], st_comp));
 	// ---- the chunk before this one: results -> host (after this chunk's work is queued,
 	// so that a copy into pageable memory, which blocks this thread, hides behind it)
 	if ( ci >= 1 ) {
@@ -485,9 +503,17 @@ int run_job( mifsk_ctx *ctx, Job &job )
     rc = copy_out(chunks.size() - 1);
     if ( rc )
 	return rc;
-    HIP_OK(hipStreamSynchronize(w->s_out));
-    HIP_OK(hipStreamSynchronize(w->s_comp));
-    HIP_OK(hipStreamSynchronize(w->s_in));
+    const double t_queued = now_s();
+    if ( !single )
+	HIP_OK(hipStreamSynchronize(w->s_out));
+    HIP_OK(hipStreamSynchronize(st_comp));
+    if ( !single )
+	HIP_OK(hipStreamSynchronize(w->s_in));
+    if ( timing )
+	std::fprintf(stderr, "### TIMING job of %zu rows: streams + events %.1f ms, pinned + device buffers %.1f ms, "
+			     "read + queue (incl. the first launch: code object, tables) %.1f ms, device until done %.1f ms\n",
+		     nrows, 1e3 * ( t_begin - t_enter ), 1e3 * ( t_alloc - t_begin ), 1e3 * ( t_queued - t_alloc ),
+		     1e3 * ( now_s() - t_queued ));
     if ( job.stats ) {
 	mifsk_host_stats &st = *job.stats;
 	st.seconds_total += now_s() - t_begin;
