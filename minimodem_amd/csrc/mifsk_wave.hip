@@ -1845,6 +1845,18 @@ bool plan_for( const DevCfg &cfg, const WaveHostArgs &ha, int sv, size_t budget,
 		if ( g.slab_cap < slab_cap )
 		    g.slab_cap = slab_cap;
 	    }
+	    // DIRECT blocks of short windows (SAME) stream every lane's window from global memory,
+	    // and the frames behind a refinement are read AGAIN by the block after it -- on a signal
+	    // that is refined every fifth frame (SAME's 8-bit frames without start / stop bits) a
+	    // block of a full pass of lanes (8 frames) throws three of them away: 2.3 x the
+	    // algorithmic bytes moved, at 4.6 TB/s of fabric traffic.  A pass of lanes costs the
+	    // same half full, so after a break the next block is as long as the lattice held last
+	    // time, down to four frames (same-box: 7.46 -> 7.07 ms; 3, 5, 6: 7.23, 7.27, 7.21).
+	    if ( g.lat_mode == LAT_DIRECT && !g.tiled && g.lat_fmin > 4u )
+		g.lat_fmin = 4u;
+	    if ( const char *e = experiment_env("MIFSK_LAT_FMIN") )	// experiments only
+		if ( std::atoi(e) >= 1 )
+		    g.lat_fmin = (uint32_t)std::atoi(e);
 	    out.g = g;
 	    out.sv = sv;
 	    out.lds_bytes = total;
