@@ -466,8 +466,11 @@ def timed_workload(name, args, M, torch, dist, ctx, pipeline, rank, world, steps
     # that many columns, not the whole frames_cap-wide buffer
     cols = int(M.max_frames(cfg, nsamp if lens is None else int(lens.max())))
     rows = [M.shard_range(total_streams, r, world)[1] - M.shard_range(total_streams, r, world)[0] for r in range(world)]
-    gatherer = M.ByteGatherer(dist, rank, world, cols=min(cols, frames_cap), rows=rows, slots=max(2, nbuf),
-                              loopback=args.gather_self and world == 1)
+    # (--native-gather: the same exchange through the library's own entry, mifsk_gather_* -- RCCL
+    # opened by libmifsk, a communicator of its own, the gather enqueued on the lane's stream)
+    Gatherer = M.NativeGatherer if args.native_gather else M.ByteGatherer
+    gatherer = Gatherer(dist, rank, world, cols=min(cols, frames_cap), rows=rows, slots=max(2, nbuf),
+                        loopback=args.gather_self and world == 1)
     failure = [None]
     wait_s = [0.0]
 
@@ -743,6 +746,8 @@ def timed_workload(name, args, M, torch, dist, ctx, pipeline, rank, world, steps
             line["payload_roundtrip_ok_streams_gathered_from_peers"] = "%d/%d" % (peers_ok, peers_judged)
         if gather_self_ok is not None:
             line["gather_self_ok"] = gather_self_ok
+        if world > 1 or args.gather_self:
+            line["gather_through"] = "mifsk_gather_* (C ABI)" if args.native_gather else "torch.distributed (ByteGatherer)"
         if per_rank is not None:
             line["per_rank"] = per_rank
             line["ranks"] = {"world_size": int(dist.get_world_size()), "backend": str(dist.get_backend())}
@@ -924,6 +929,9 @@ def main():
     ap.add_argument("--gather-self", action="store_true",
                     help="N = 1 only: run the N > 1 step structure anyway -- process group on the nccl "
                          "backend, the gather of every pass as a send to this rank itself on the lane's stream")
+    ap.add_argument("--native-gather", action="store_true",
+                    help="N > 1 (or --gather-self): gather through mifsk_gather_* (C ABI, RCCL opened by the "
+                         "library) instead of torch.distributed's grouped isend / irecv")
     ap.add_argument("--engine", default=None, choices=["wave", "workgroup"],
                     help="force a receive-loop engine (default: the library chooses)")
     args = ap.parse_args()

@@ -22,6 +22,7 @@
  *   mifsk_find_frame_batch        fsk_find_frame         fsk.c:449-538 (N problems)
  *   mifsk_demod_batch             the --rx main loop     minimodem.c:1137-1463
  *   mifsk_pipeline_*              ... several batches in flight (lanes of context + stream)
+ *   mifsk_gather_*                (none: one process per GPU) decoded bytes to rank 0, RCCL
  *   mifsk_demod_batch_host[_ex]   same, host buffers     (chunked H2D | demod | D2H, overlapped)
  *   mifsk_demod_files             --rx --file, N files   simpleaudio-sndfile.c:42-74,
  *                                                        minimodem.c:1014-1032
@@ -380,6 +381,56 @@ int  mifsk_pipeline_drain( mifsk_pipeline *p );
 /* the lane of pass `ticket`: its hipStream_t and its context */
 void *mifsk_pipeline_stream( mifsk_pipeline *p, uint64_t ticket );
 mifsk_ctx *mifsk_pipeline_ctx( mifsk_pipeline *p, uint64_t ticket );
+
+/* ---- one process per GPU: decoded bytes to one rank -------------------------- */
+
+/* Streams are independent: rank r of `world` demodulates mifsk_shard_range(nstreams, r, world)
+ * and nothing is exchanged on the way.  Where ONE rank must end up holding every stream's bytes
+ * (a job launched as one process per GPU; the reference is one process and has no counterpart,
+ * src/minimodem.c:1014-1032), the results are gathered to rank 0 over RCCL: every peer sends on
+ * its own xGMI link, the root posts all its receives as one group.  RCCL is opened at run time
+ * (dlopen of librccl.so.1, the copy the process already has if there is one) and only by these
+ * calls: -ENOSYS when it cannot be.
+ *
+ * Rendezvous: rank 0 makes an id (mifsk_gather_unique_id) and the job's launcher carries its
+ * MIFSK_GATHER_ID_BYTES bytes to every rank (MPI, a socket, torch.distributed, a file); every
+ * rank then calls mifsk_gather_create -- a collective call, like ncclCommInitRank.
+ *
+ * mifsk_gather_start enqueues ONE gather on `stream` behind whatever produced the arrays there
+ * (the lane's stream of a pipeline pass: mifsk_pipeline_stream) and returns its ticket; it is
+ * complete when `stream` reaches the point behind the call.  Only the first `cols` columns of
+ * every [row_pitch]-wide row travel (a stream's bytes cannot exceed mifsk_max_frames of its
+ * length), through a dense staging copy made on `stream`.  rows[world]: streams per rank (NULL:
+ * every rank holds `nstreams`).  The root keeps `slots` receive sets and the k-th gather fills
+ * set k % slots, the senders as many staging copies: with up to `slots` gathers in flight none
+ * overwrites what an older one delivered.  mifsk_gather_received (rank 0) names what peer
+ * `peer` >= 1 sent in gather `ticket`: rows x cols bytes, dense, and the counts.
+ *
+ * MIFSK_GATHER_LOOPBACK (world == 1 only): the one rank sends to ITSELF through the same calls
+ * and receives it as peer 0 -- the whole transport on one GPU (tests/test_gpu_gather.py).
+ * Without it a world of one makes no communicator and start() has nothing to do. */
+typedef struct mifsk_gather mifsk_gather;
+#define MIFSK_GATHER_ID_BYTES	128
+#define MIFSK_GATHER_LOOPBACK	1u
+
+typedef struct mifsk_gather_info {
+    int		rank, world, device;
+    uint32_t	slots;
+    uint32_t	loopback;
+    uint32_t	communicator;	/* 1: an RCCL communicator was made */
+} mifsk_gather_info;
+
+int  mifsk_gather_unique_id( void *id /* [MIFSK_GATHER_ID_BYTES] */ );
+/* device < 0: the current HIP device; slots clamped to 2 .. 16 */
+int  mifsk_gather_create( mifsk_gather **out, const void *id, int rank, int world, int device,
+	int slots, unsigned flags );
+void mifsk_gather_destroy( mifsk_gather *g );	/* synchronises the device first */
+int  mifsk_gather_info_get( const mifsk_gather *g, mifsk_gather_info *info );
+int  mifsk_gather_start( mifsk_gather *g, const uint8_t *d_bytes, size_t row_pitch,
+	const int32_t *d_nbytes, int nstreams, int cols, const int *rows, void *stream,
+	uint64_t *ticket );
+int  mifsk_gather_received( mifsk_gather *g, uint64_t ticket, int peer,
+	const uint8_t **d_bytes, const int32_t **d_nbytes, int *rows, int *cols );
 
 /* What mifsk_demod_batch would launch for `cfg`, a batch of `nstreams` streams and
  * `flags` (MIFSK_IO_*): the kernel instantiation, its launch geometry and the

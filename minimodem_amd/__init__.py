@@ -630,6 +630,99 @@ class ByteGatherer:
         return self._rx[self._last if slot is None else slot % self.slots][0 if self.loopback else r - 1]
 
 
+class NativeGatherer:
+    """mifsk_gather_*: the same gather behind the C ABI (csrc/mifsk_gather.cpp: RCCL opened with
+    dlopen, a communicator of the library's own).  Interface of ByteGatherer -- start(bytes,
+    nbytes) enqueues ONE gather on torch's current stream and returns no handles (it is complete
+    when that stream reaches the point behind the call); received(r, slot) on rank 0 is what peer
+    r sent in the gather that filled set `slot` (default: the most recently started one), as torch
+    views of the library's receive set.
+
+    `dist`: a torch.distributed module whose default group carries rank 0's id to the others
+    (None at world size 1); the communicator itself is made by the library."""
+
+    def __init__(self, dist, rank, world, cols=None, rows=None, slots=2, loopback=False, device=-1):
+        torch = _torch()
+        self._lib = _lib.load()
+        self.rank, self.world = int(rank), int(world)
+        self.cols, self.rows = cols, rows
+        self.loopback = bool(loopback) and world == 1
+        self.slots = max(2, int(slots))
+        self._tickets = []
+        ident = None
+        if world > 1 or self.loopback:
+            buf = (C.c_ubyte * _lib.GATHER_ID_BYTES)()
+            if rank == 0:
+                rc = self._lib.mifsk_gather_unique_id(buf)
+                if rc != 0:
+                    raise RuntimeError("mifsk_gather_unique_id failed: %d" % rc)
+            if world > 1:
+                # (through the job's own process group: on the device for RCCL, on the host for gloo)
+                dev = "cuda" if str(dist.get_backend()) == "nccl" else "cpu"
+                t = torch.tensor(list(bytes(buf)), dtype=torch.uint8, device=dev)
+                dist.broadcast(t, src=0)
+                buf = (C.c_ubyte * _lib.GATHER_ID_BYTES)(*t.cpu().tolist())
+            ident = buf
+        h = C.c_void_p()
+        rc = self._lib.mifsk_gather_create(C.byref(h), ident, self.rank, self.world, int(device), self.slots,
+                                           _lib.GATHER_LOOPBACK if self.loopback else 0)
+        if rc != 0:
+            raise RuntimeError("mifsk_gather_create failed: %d" % rc)
+        self.handle = h
+
+    def info(self):
+        gi = _lib.GatherInfo()
+        self._lib.mifsk_gather_info_get(self.handle, C.byref(gi))
+        return {k: int(getattr(gi, k)) for k, _ in gi._fields_}
+
+    def bytes_per_peer(self, nstreams):
+        return int(nstreams) * (int(self.cols) if self.cols else 0) + 4 * int(nstreams)
+
+    def start(self, local_bytes, local_nbytes):
+        torch = _torch()
+        cols = local_bytes.shape[1] if self.cols is None else min(int(self.cols), local_bytes.shape[1])
+        self.cols = cols
+        assert local_bytes.dtype == torch.uint8 and local_nbytes.dtype == torch.int32 and local_bytes.stride(1) == 1
+        rows = None
+        if self.rows is not None and not self.loopback:
+            rows = (C.c_int * self.world)(*[int(r) for r in self.rows])
+        tk = C.c_uint64()
+        rc = self._lib.mifsk_gather_start(self.handle, C.c_void_p(local_bytes.data_ptr()), int(local_bytes.stride(0)),
+                                          C.c_void_p(local_nbytes.data_ptr()), int(local_bytes.shape[0]), cols, rows,
+                                          _stream_ptr(torch, torch.cuda.current_stream()), C.byref(tk))
+        if rc != 0:
+            raise RuntimeError("mifsk_gather_start failed: %d" % rc)
+        self._tickets.append(int(tk.value))
+        del self._tickets[:-self.slots]
+        return []
+
+    def received(self, r, slot=None):
+        torch = _torch()
+        tk = self._tickets[-1]
+        if slot is not None:
+            tk = [t for t in self._tickets if t % self.slots == slot % self.slots][-1]
+        pb, pn, rows, cols = C.c_void_p(), C.c_void_p(), C.c_int(), C.c_int()
+        rc = self._lib.mifsk_gather_received(self.handle, tk, 0 if self.loopback else int(r), C.byref(pb), C.byref(pn),
+                                             C.byref(rows), C.byref(cols))
+        if rc != 0:
+            raise RuntimeError("mifsk_gather_received failed: %d" % rc)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        b = torch.as_tensor(_DevArray(pb.value, (rows.value, cols.value), "|u1"), device=dev)
+        n = torch.as_tensor(_DevArray(pn.value, (rows.value,), "<i4"), device=dev)
+        return b, n
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.mifsk_gather_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:		# noqa: BLE001
+            pass
+
+
 DECODERS = {"ascii8": 0, "baudot": 1, "binary": 2, "callerid": 3, "uic-ground": 4, "uic-train": 5}
 TEXT_PRINT_FILTER = 1
 TEXT_QUIET = 2

@@ -152,6 +152,13 @@ class PipelineInfo(C.Structure):
                 ("hw_queues", C.c_uint32), ("output_sets", C.c_uint32)]
 
 
+class GatherInfo(C.Structure):
+    _fields_ = [("rank", C.c_int), ("world", C.c_int), ("device", C.c_int),
+                ("slots", C.c_uint32), ("loopback", C.c_uint32), ("communicator", C.c_uint32)]
+
+
+GATHER_ID_BYTES = 128
+GATHER_LOOPBACK = 1
 WANT_BYTES, WANT_BITS, WANT_FRAMES, WANT_EPISODES = 1, 2, 4, 8
 PIPELINE_NO_PRODUCER = C.c_void_p(-1)
 IO_RING_EXACT = 1
@@ -225,6 +232,8 @@ EXPORTS = [
     "mifsk_pipeline_outputs_alloc", "mifsk_pipeline_outputs_get", "mifsk_pipeline_submit",
     "mifsk_pipeline_next_ticket", "mifsk_pipeline_wait", "mifsk_pipeline_join",
     "mifsk_pipeline_drain", "mifsk_pipeline_stream", "mifsk_pipeline_ctx",
+    "mifsk_gather_unique_id", "mifsk_gather_create", "mifsk_gather_destroy", "mifsk_gather_info_get",
+    "mifsk_gather_start", "mifsk_gather_received",
 ]
 
 _lib = None
@@ -369,6 +378,20 @@ def load():
     lib.mifsk_pipeline_stream.argtypes = [C.c_void_p, C.c_uint64]
     lib.mifsk_pipeline_ctx.restype = C.c_void_p
     lib.mifsk_pipeline_ctx.argtypes = [C.c_void_p, C.c_uint64]
+    lib.mifsk_gather_unique_id.restype = C.c_int
+    lib.mifsk_gather_unique_id.argtypes = [C.c_void_p]
+    lib.mifsk_gather_create.restype = C.c_int
+    lib.mifsk_gather_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint]
+    lib.mifsk_gather_destroy.restype = None
+    lib.mifsk_gather_destroy.argtypes = [C.c_void_p]
+    lib.mifsk_gather_info_get.restype = C.c_int
+    lib.mifsk_gather_info_get.argtypes = [C.c_void_p, C.POINTER(GatherInfo)]
+    lib.mifsk_gather_start.restype = C.c_int
+    lib.mifsk_gather_start.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int,
+                                       C.POINTER(C.c_int), C.c_void_p, C.POINTER(C.c_uint64)]
+    lib.mifsk_gather_received.restype = C.c_int
+    lib.mifsk_gather_received.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_void_p),
+                                          C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.mifsk_selftest_sqrt.restype = C.c_int
     lib.mifsk_selftest_sqrt.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
     _lib = lib

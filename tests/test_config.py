@@ -158,7 +158,7 @@ def test_struct_layouts_match_between_bindings():
     lib = _lib.load()
     mirror = {"mifsk_modem_args": _lib.ModemArgs, "mifsk_rx_config": _lib.RxConfig, "mifsk_search": _lib.Search,
               "mifsk_search_result": _lib.SearchResult, "mifsk_demod_io": _lib.DemodIO,
-              "mifsk_launch_info": _lib.LaunchInfo, "mifsk_pipeline_info": _lib.PipelineInfo, "mifsk_scan_plan": _lib.ScanPlan,
+              "mifsk_launch_info": _lib.LaunchInfo, "mifsk_pipeline_info": _lib.PipelineInfo, "mifsk_gather_info": _lib.GatherInfo, "mifsk_scan_plan": _lib.ScanPlan,
               "mifsk_host_stats": _lib.HostStats, "mifsk_wav_info": _lib.WavInfo,
               "mifsk_file_result": _lib.FileResult, "fsk_plan": _lib.FskPlan}
     for name, t in mirror.items():
@@ -179,3 +179,23 @@ def test_stream_padding_is_the_search_reach():
         reach = max(cfg.try_max[0], cfg.try_max[1])
         last = cfg.bit_offset[cfg.expect_n_bits - 1] + cfg.bit_nsamples
         assert lib.mifsk_stream_padding(C.byref(cfg)) == (reach + last + 3) & ~3
+
+
+def test_gather_entry_checks_its_arguments_before_it_touches_a_device():
+    """mifsk_gather_create (include/mifsk.h): -EINVAL for a rank outside the world, a world of
+    several without the id, loopback outside a world of one -- decided before any HIP or RCCL
+    call; with sound arguments the device decides (-ENODEV on a box without one)."""
+    import torch
+    lib = _lib.load()
+    h = C.c_void_p()
+    ident = (C.c_ubyte * _lib.GATHER_ID_BYTES)()
+    assert lib.mifsk_gather_create(None, ident, 0, 1, -1, 2, 0) == -22
+    assert lib.mifsk_gather_create(C.byref(h), ident, 2, 2, -1, 2, 0) == -22
+    assert lib.mifsk_gather_create(C.byref(h), None, 0, 2, -1, 2, 0) == -22
+    assert lib.mifsk_gather_create(C.byref(h), ident, 0, 2, -1, 2, _lib.GATHER_LOOPBACK) == -22
+    assert lib.mifsk_gather_create(C.byref(h), ident, 0, 1, -1, 2, 2) == -22
+    assert lib.mifsk_gather_unique_id(None) == -22
+    assert lib.mifsk_gather_start(None, None, 0, None, 0, 0, None, None, None) == -22
+    assert lib.mifsk_gather_received(None, 0, 0, None, None, None, None) == -22
+    if not torch.cuda.is_available():
+        assert lib.mifsk_gather_create(C.byref(h), None, 0, 1, -1, 2, 0) == -19 and not h.value

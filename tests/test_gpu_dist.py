@@ -82,14 +82,16 @@ def test_bench_step_structure_of_n_gt_1_on_one_gpu_with_the_gather_sent_to_itsel
     env = dict(os.environ)
     env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29519", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    for cfg, streams in (("1200", 512), ("12000", 1024)):
+    # (the last one with the gather behind the C ABI: mifsk_gather_*, bench.py --native-gather)
+    for cfg, streams, extra in (("1200", 512, []), ("12000", 1024, []), ("1200", 512, ["--native-gather"])):
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", cfg, "--streams", str(streams),
                             "--steps", "8", "--warmup", "2", "--gather-self", "--no-cpu", "--no-h2d",
-                            "--preheat-ms", "50"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                            "--preheat-ms", "50"] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                            timeout=600, cwd=root, env=env)
         assert r.returncode == 0, r.stderr.decode()[-3000:]
         line = json.loads(r.stdout.decode().strip().splitlines()[-1])
         assert line["n_gpus"] == 1 and line["gather_self_ok"] is True
+        assert line["gather_through"].startswith("mifsk_gather_" if extra else "torch.distributed")
         assert line["ranks"] == {"world_size": 1, "backend": "nccl"}
         pr = line["per_rank"]
         assert len(pr["kernel_ms_avg"]) == 1 and pr["kernel_ms_avg"][0] > 0
