@@ -23,6 +23,8 @@
  *   mifsk_demod_batch             the --rx main loop     minimodem.c:1137-1463
  *   mifsk_pipeline_*              ... several batches in flight (lanes of context + stream)
  *   mifsk_gather_*                (none: one process per GPU) decoded bytes to rank 0, RCCL
+ *   mifsk_demod_slab[_ring]       the loop over a stream that arrives in pieces  minimodem.c:1144-1174
+ *   mifsk_session_*               ... fed from host memory, bookkeeping included
  *   mifsk_demod_batch_host[_ex]   same, host buffers     (chunked H2D | demod | D2H, overlapped)
  *   mifsk_demod_files             --rx --file, N files   simpleaudio-sndfile.c:42-74,
  *                                                        minimodem.c:1014-1032
@@ -585,6 +587,46 @@ size_t mifsk_ring_floats( const mifsk_rx_config *cfg );
 int mifsk_demod_slab_ring( mifsk_ctx *ctx, const mifsk_rx_config *cfg, const mifsk_demod_io *io,
 	mifsk_stream_state *d_state, const uint64_t *d_origin, float *d_ring, int final,
 	void *stream );
+
+/* ---- streams fed in pieces from host memory ---------------------------------- */
+
+/* mifsk_demod_slab with the bookkeeping done (reference: the loop that reads its stream half a
+ * samplebuf at a time, src/minimodem.c:1144-1174 -- a recording longer than memory, live audio).
+ * A session holds `nstreams` streams: per stream the samples the loop has not passed yet (host
+ * memory), where they start in the stream, the loop state and (RING) the samplebuf cells on the
+ * device, and arrays sized for every feed.  mifsk_session_feed takes each stream's NEW samples
+ * -- samples[s] / nsamples[s], any amount, none (NULL / 0) included -- runs the loop as far as
+ * the data allows (`final`: no more will come, the rows' ends are the streams' ends) and waits
+ * for the results: mifsk_session_get(s, i) is what THIS feed made of stream i -- frames in loop
+ * order, episodes as they end, frame starts and episode frame indices counted from the start of
+ * the stream -- in host memory the session owns, valid until the next feed.  Any cut gives,
+ * concatenated, the results of one call over the whole streams, bit for bit.
+ * flags: MIFSK_IO_RING_EXACT (the reference's buffer semantics across the feeds: `minimodem
+ * --rx --file`'s frames digit for digit), MIFSK_IO_ENGINE_*, MIFSK_SESSION_WANT_FRAMES.
+ * One feed at a time per session; sessions on one context are ordered by the caller. */
+typedef struct mifsk_session mifsk_session;
+#define MIFSK_SESSION_WANT_FRAMES	0x1000u	/* the per-frame records too */
+
+typedef struct mifsk_session_result {
+    uint32_t		nframes, nbytes, nepisodes;	/* of this feed */
+    uint32_t		status;		/* MIFSK_STREAM_* of this feed                 */
+    int32_t		carrier_band;	/* --auto-carrier (see mifsk_demod_io)         */
+    uint32_t		finished;	/* 1: the final piece has been decoded         */
+    const uint64_t	*bits;		/* [nframes] data bits of every frame          */
+    const uint8_t	*bytes;		/* [nbytes]                                    */
+    const mifsk_frame	*frames;	/* [nframes], or NULL without WANT_FRAMES      */
+    const mifsk_episode	*episodes;	/* [nepisodes]                                 */
+    uint64_t		consumed;	/* stream index the loop has passed for good   */
+} mifsk_session_result;
+
+int  mifsk_session_create( mifsk_session **out, mifsk_ctx *ctx, const mifsk_rx_config *cfg,
+	int nstreams, unsigned flags );
+void mifsk_session_destroy( mifsk_session *s );
+int  mifsk_session_feed( mifsk_session *s, const float *const *samples, const uint32_t *nsamples,
+	int final );
+const mifsk_session_result *mifsk_session_get( const mifsk_session *s, int stream );
+/* samples of stream `stream` the session still holds (fed, not yet passed by the loop) */
+size_t mifsk_session_pending( const mifsk_session *s, int stream );
 
 /* ---- several GPUs (SURVEY 8 e) -------------------------------------------- */
 

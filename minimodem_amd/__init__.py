@@ -1134,6 +1134,58 @@ class SlabSession:
         return res
 
 
+class Session:
+    """mifsk_session_*: SlabSession's job behind the C ABI (csrc/mifsk_session.cpp) -- the
+    unconsumed tails, origins, loop state, RING cells and output arrays are the library's.
+    feed(new, final) returns one dict per stream of what THIS feed made of it (numpy copies)."""
+
+    def __init__(self, ctx, cfg, nstreams, engine=None, ring_exact=False, want_frames=True):
+        self._lib = _lib.load()
+        self.n = int(nstreams)
+        flags = (_lib.IO_ENGINE_WORKGROUP if engine == "workgroup" else 0) | (_lib.IO_ENGINE_WAVE if engine == "wave" else 0) \
+            | (_lib.IO_RING_EXACT if ring_exact else 0) | (_lib.SESSION_WANT_FRAMES if want_frames else 0)
+        h = C.c_void_p()
+        rc = self._lib.mifsk_session_create(C.byref(h), ctx.handle, C.byref(cfg), self.n, flags)
+        if rc != 0:
+            raise RuntimeError("mifsk_session_create failed: %d" % rc)
+        self.handle = h
+
+    def feed(self, new, final=False):
+        assert len(new) == self.n
+        keep = [np.ascontiguousarray(x, dtype=np.float32) if x is not None and len(x) else None for x in new]
+        ptrs = (C.c_void_p * self.n)(*[k.ctypes.data if k is not None else None for k in keep])
+        cnts = (C.c_uint32 * self.n)(*[len(k) if k is not None else 0 for k in keep])
+        rc = self._lib.mifsk_session_feed(self.handle, ptrs, cnts, 1 if final else 0)
+        if rc != 0:
+            raise RuntimeError("mifsk_session_feed failed: %d" % rc)
+        out = []
+        for i in range(self.n):
+            r = self._lib.mifsk_session_get(self.handle, i).contents
+
+            def arr(ptr, count, dtype):
+                if not ptr or not count:
+                    return np.zeros(0, dtype)
+                nb = count * np.dtype(dtype).itemsize
+                return np.frombuffer(C.string_at(ptr, nb), dtype=dtype).copy()
+            out.append({"frames": arr(r.frames, r.nframes, FRAME_DTYPE), "bits": arr(r.bits, r.nframes, np.uint64),
+                        "bytes": arr(r.bytes, r.nbytes, np.uint8).tobytes(),
+                        "episodes": arr(r.episodes, r.nepisodes, EPISODE_DTYPE), "status": int(r.status),
+                        "carrier_band": int(r.carrier_band), "consumed": int(r.consumed), "finished": bool(r.finished),
+                        "pending": int(self._lib.mifsk_session_pending(self.handle, i))})
+        return out
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.mifsk_session_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:		# noqa: BLE001
+            pass
+
+
 def scan_plan(cfg, kind):
     """mifsk_scan_plan_get: the shared-segment plan of scan `kind` (2 * fine + carrier) as a dict
     of numpy arrays, or None when that scan correlates every window by itself."""

@@ -157,6 +157,14 @@ class GatherInfo(C.Structure):
                 ("slots", C.c_uint32), ("loopback", C.c_uint32), ("communicator", C.c_uint32)]
 
 
+class SessionResult(C.Structure):
+    _fields_ = [("nframes", C.c_uint32), ("nbytes", C.c_uint32), ("nepisodes", C.c_uint32),
+                ("status", C.c_uint32), ("carrier_band", C.c_int32), ("finished", C.c_uint32),
+                ("bits", C.c_void_p), ("bytes", C.c_void_p), ("frames", C.c_void_p),
+                ("episodes", C.c_void_p), ("consumed", C.c_uint64)]
+
+
+SESSION_WANT_FRAMES = 0x1000
 GATHER_ID_BYTES = 128
 GATHER_LOOPBACK = 1
 WANT_BYTES, WANT_BITS, WANT_FRAMES, WANT_EPISODES = 1, 2, 4, 8
@@ -234,6 +242,8 @@ EXPORTS = [
     "mifsk_pipeline_drain", "mifsk_pipeline_stream", "mifsk_pipeline_ctx",
     "mifsk_gather_unique_id", "mifsk_gather_create", "mifsk_gather_destroy", "mifsk_gather_info_get",
     "mifsk_gather_start", "mifsk_gather_received",
+    "mifsk_session_create", "mifsk_session_destroy", "mifsk_session_feed", "mifsk_session_get",
+    "mifsk_session_pending",
 ]
 
 _lib = None
@@ -392,6 +402,16 @@ def load():
     lib.mifsk_gather_received.restype = C.c_int
     lib.mifsk_gather_received.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_void_p),
                                           C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.mifsk_session_create.restype = C.c_int
+    lib.mifsk_session_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(RxConfig), C.c_int, C.c_uint]
+    lib.mifsk_session_destroy.restype = None
+    lib.mifsk_session_destroy.argtypes = [C.c_void_p]
+    lib.mifsk_session_feed.restype = C.c_int
+    lib.mifsk_session_feed.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_int]
+    lib.mifsk_session_get.restype = C.POINTER(SessionResult)
+    lib.mifsk_session_get.argtypes = [C.c_void_p, C.c_int]
+    lib.mifsk_session_pending.restype = C.c_size_t
+    lib.mifsk_session_pending.argtypes = [C.c_void_p, C.c_int]
     lib.mifsk_selftest_sqrt.restype = C.c_int
     lib.mifsk_selftest_sqrt.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
     _lib = lib

@@ -369,6 +369,7 @@ extern "C" size_t mifsk_abi_sizeof( const char *name )
     MIFSK_SIZEOF(mifsk_launch_info);
     MIFSK_SIZEOF(mifsk_pipeline_info);
     MIFSK_SIZEOF(mifsk_gather_info);
+    MIFSK_SIZEOF(mifsk_session_result);
     MIFSK_SIZEOF(mifsk_scan_plan);
     MIFSK_SIZEOF(mifsk_host_stats);
     MIFSK_SIZEOF(mifsk_stream_state);

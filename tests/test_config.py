@@ -158,7 +158,7 @@ def test_struct_layouts_match_between_bindings():
     lib = _lib.load()
     mirror = {"mifsk_modem_args": _lib.ModemArgs, "mifsk_rx_config": _lib.RxConfig, "mifsk_search": _lib.Search,
               "mifsk_search_result": _lib.SearchResult, "mifsk_demod_io": _lib.DemodIO,
-              "mifsk_launch_info": _lib.LaunchInfo, "mifsk_pipeline_info": _lib.PipelineInfo, "mifsk_gather_info": _lib.GatherInfo, "mifsk_scan_plan": _lib.ScanPlan,
+              "mifsk_launch_info": _lib.LaunchInfo, "mifsk_pipeline_info": _lib.PipelineInfo, "mifsk_gather_info": _lib.GatherInfo, "mifsk_session_result": _lib.SessionResult, "mifsk_scan_plan": _lib.ScanPlan,
               "mifsk_host_stats": _lib.HostStats, "mifsk_wav_info": _lib.WavInfo,
               "mifsk_file_result": _lib.FileResult, "fsk_plan": _lib.FskPlan}
     for name, t in mirror.items():
