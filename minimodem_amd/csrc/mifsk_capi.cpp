@@ -175,7 +175,8 @@ static void plan_segments( SegPlan &sp, const mifsk_rx_config &c, const std::vec
     // DESIGN.md "shared segments": index-order rounding (B - 1) + segment sums
     // sqrt(2) (L - 1) + assembly 2 n + table entries' own rounding 85, in units of
     // 2^-53 * sum |x|; rounded up generously
-    sp.bound_c = (float)( B + 1.5 * lmax + 2.0 * cmax + 128.0 );
+    // (+ 2: a short scan's windows are assembled as two half sums and one more addition)
+    sp.bound_c = (float)( B + 1.5 * lmax + 2.0 * cmax + 2.0 + 128.0 );
     // (a pass loads table group ceil(L / 16) + 3 at most; the table has ceil(B / 16) + 1)
     if ( ( lmax + 15 ) / 16 + 3 > ( B + 15 ) / 16 )
 	return;
@@ -573,7 +574,10 @@ static int get_devcfg( mifsk_ctx *ctx, const DevCfg &d, const DevCfg **d_out, Cf
 	for ( unsigned w = 0; w < sp.nwin; w++ )
 	    cmax = sp.win_count[w] > cmax ? sp.win_count[w] : cmax;
 	const unsigned stride = ( sp.nwin + 63u ) & ~63u;
-	std::vector<double> h((size_t)cmax * stride * 4, 0.0);
+	// (zero rows beyond the longest window's: Wave::seg_correlate walks the rows with a running
+	// pointer, four segments a turn, and where two lanes share a window -- every other row each --
+	// up to 2 x 3 + 1 rows beyond the last)
+	std::vector<double> h((size_t)( ( cmax + 12u + 3u ) & ~3u ) * stride * 4, 0.0);
 	for ( unsigned w = 0; w < sp.nwin; w++ )
 	    for ( unsigned i = 0; i < sp.win_count[w]; i++ ) {
 		const unsigned off = sp.seg_rel[sp.win_first[w] + i] - ( sp.p_win[w] >> 16 );

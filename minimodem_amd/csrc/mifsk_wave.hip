@@ -783,8 +783,14 @@ struct Wave {
 	// are float sums: a little slack)
 	const double dscale = (double)sp.bound_c * 1.0001 * 1.1102230246251565e-16 * sqrt((double)B);
 	unsigned long long redo0 = 0ull, redo1 = 0ull;
+	// A scan of at most 32 windows (the carrier-held coarse scan: 3 candidates) would leave half
+	// the lanes idle: each window's segments are then shared by TWO lanes -- lane w takes the
+	// even ones, lane 32 + w the odd ones -- and the two halves are added at the end (another
+	// order of the same sum: two more roundings, counted in the plan's bound_c).
+	const bool split = rot != nullptr && nwin_scan <= 32u;
 	for ( uint32_t g0 = 0; g0 < nwin_scan; g0 += 64u ) {
-	    const uint32_t w = g0 + lane;
+	    const uint32_t part = split ? lane >> 5 : 0u;
+	    const uint32_t w = split ? ( lane & 31u ) : g0 + lane;
 	    const bool active = w < nwin_scan;
 	    const uint32_t wl = active ? w : 0u;		// the scan's window ...
 	    const uint32_t ww = w_off + wl;			// ... is this one of the plan
@@ -795,6 +801,48 @@ struct Wave {
 	    double mr = 0.0, mi = 0.0, sr = 0.0, si = 0.0;
 	    float aw = 0.0f;
 	    constexpr int AU = 4;			// segments per turn, every load issued before the first use
+	    if ( rot ) {
+		// rotation factors from the scan's own table, laid out for this loop: row i holds
+		// segment i of every window, lanes read side by side, rows beyond a window's own
+		// segments (and up to three turns beyond the longest window's) hold zeros
+		// (mifsk_capi.cpp) -- a running pointer, no row arithmetic per segment
+		const uint32_t stepi = split ? 2u : 1u;
+		const double *tp = rot + 4 * ( (size_t)ww + (size_t)part * rstride );
+		const size_t tstep = 4 * (size_t)rstride * stepi;
+		const uint32_t turns = split ? ( cmax + 1u ) >> 1 : cmax;
+		for ( uint32_t i0 = 0; i0 < turns; i0 += (uint32_t)AU ) {
+		    double2_a16 p0[AU], p1[AU], t0[AU], t1[AU];
+		    float as[AU];
+#pragma unroll
+		    for ( int u = 0; u < AU; u++ ) {
+			const uint32_t i = ( i0 + (uint32_t)u ) * stepi + part;
+			const uint32_t s = i < cnt ? first + i : (uint32_t)SEG_MAX;	// (beyond its own: the zero entry)
+			p0[u] = *reinterpret_cast<const double2_a16 *>(partD + 4u * s);
+			p1[u] = *reinterpret_cast<const double2_a16 *>(partD + 4u * s + 2u);
+			as[u] = partA[s];
+			t0[u] = *reinterpret_cast<const double2_a16 *>(tp);
+			t1[u] = *reinterpret_cast<const double2_a16 *>(tp + 2);
+			tp += tstep;
+		    }
+#pragma unroll
+		    for ( int u = 0; u < AU; u++ ) {
+			const double Sr = p0[u].x, Si = p0[u].y, Tr = p1[u].x, Ti = p1[u].y;
+			// (Sr + i Si) (c + i m),  (c, m) = (cos, -sin) of the offset
+			mr = fma(Sr, t0[u].x, mr);  mr = fma(-Si, t0[u].y, mr);
+			mi = fma(Sr, t0[u].y, mi);  mi = fma(Si, t0[u].x, mi);
+			sr = fma(Tr, t1[u].x, sr);  sr = fma(-Ti, t1[u].y, sr);
+			si = fma(Tr, t1[u].y, si);  si = fma(Ti, t1[u].x, si);
+			aw += as[u];
+		    }
+		}
+		if ( split ) {
+		    mr += __shfl_xor(mr, 32);
+		    mi += __shfl_xor(mi, 32);
+		    sr += __shfl_xor(sr, 32);
+		    si += __shfl_xor(si, 32);
+		    aw += __shfl_xor(aw, 32);
+		}
+	    } else
 	    for ( uint32_t i0 = 0; i0 < cmax; i0 += (uint32_t)AU ) {
 		double2_a16 p0[AU], p1[AU], t0[AU], t1[AU];
 		float as[AU];
@@ -806,20 +854,16 @@ struct Wave {
 		    p0[u] = *reinterpret_cast<const double2_a16 *>(partD + 4u * s);
 		    p1[u] = *reinterpret_cast<const double2_a16 *>(partD + 4u * s + 2u);
 		    as[u] = partA[s];
+		    // entry d of the stream's own table (--auto-carrier: the tones are the stream's);
+		    // beyond its own segments a lane multiplies the zero entry by a factor that exists
 		    const uint32_t d = in ? partRel[s] - a_rel : 0u;	// offset of the segment inside the window
-		    // its rotation factor: from the scan's own table, laid out for this loop (lanes
-		    // read side by side), or entry d of the stream's table
-		    // (beyond its own segments a lane multiplies the zero entry: by a factor that exists --
-		    // row i of the rotation table may lie behind the table's end, and 0 x whatever bits
-		    // are there could be NaN)
-		    const double *t = rot ? rot + 4 * ( (size_t)( in ? i : 0u ) * rstride + ww ) : tw + 4 * (size_t)d;
+		    const double *t = tw + 4 * (size_t)d;
 		    t0[u] = *reinterpret_cast<const double2_a16 *>(t);
 		    t1[u] = *reinterpret_cast<const double2_a16 *>(t + 2);
 		}
 #pragma unroll
 		for ( int u = 0; u < AU; u++ ) {
 		    const double Sr = p0[u].x, Si = p0[u].y, Tr = p1[u].x, Ti = p1[u].y;
-		    // (Sr + i Si) (c + i m),  (c, m) = (cos, -sin) of the offset
 		    mr = fma(Sr, t0[u].x, mr);  mr = fma(-Si, t0[u].y, mr);
 		    mi = fma(Sr, t0[u].y, mi);  mi = fma(Si, t0[u].x, mi);
 		    sr = fma(Tr, t1[u].x, sr);  sr = fma(-Ti, t1[u].y, sr);
@@ -832,7 +876,7 @@ struct Wave {
 			     && (float)( mi - delta ) == (float)( mi + delta )
 			     && (float)( sr - delta ) == (float)( sr + delta )
 			     && (float)( si - delta ) == (float)( si + delta );
-	    const bool wanted = active && j >= c0;
+	    const bool wanted = active && j >= c0 && part == 0u;
 	    if ( wanted && stable )
 		mags[( j - c0 ) * nb + k] = band_mag2_exact(mr, mi, sr, si, cfg.magscalar);
 	    const unsigned long long again = __ballot(wanted && !stable);
