@@ -79,50 +79,174 @@ static void plan_segments( SegPlan &sp, const mifsk_rx_config &c, const std::vec
     }
     if ( segs.empty() || segs.size() > (size_t)SEG_MAX )
 	return;
-    // Balance.  Every piece may be cut further, into k equal parts; with a target length T
-    // piece i gets k_i = ceil(len_i / T) parts.  The parts go to (at most two) passes of 64
-    // lanes, longest first, and a pass costs as many groups of 16 samples as its longest
-    // part has: take the T that makes the passes cheapest.
+    // Balance.  Every piece may be cut further; the parts go to (at most two) passes of 64 lanes,
+    // longest first.  What a pass costs is decided by its longest part: whole groups of 16 samples
+    // (a group of the sums: ~86 instructions, ~118 where some lane's part ends inside it and the
+    // samples are masked) in whole tile steps of 32 (stage, read back, fetch: ~60).  Two ways of
+    // cutting are tried and the cheapest plan is taken:
+    //  * equal parts: with a target length T piece i gets ceil(len_i / T) parts (all T);
+    //  * caps (round 6): pass 0 takes parts of at most A0 samples, pass 1 of at most A1 <= A0, and
+    //    a piece is cut UNEQUALLY into n0 parts for the one and n1 for the other -- which (n0, n1)
+    //    per piece is a small dynamic program over the 64 lanes of each pass.  RTTY's carrier-held
+    //    plan (pieces of 165, 110, 66, 55, 44 samples) went from 83 + 82 | 110 whole -- 7 + 6 groups
+    //    in 4 + 3 steps -- to 101 + 64 | 110 whole: 7 + 4 groups in 4 + 2 steps.
     {
 	const std::vector<Seg> pieces = segs;
-	unsigned best_cost = 0xFFFFFFFFu, best_T = 0;
-	std::vector<unsigned> cand;
-	for ( const Seg &s : pieces )
-	    for ( unsigned k = 1; k <= 16u && s.len / k >= 16u; k++ )
-		cand.push_back(( s.len + k - 1 ) / k);
-	std::sort(cand.begin(), cand.end());
-	cand.erase(std::unique(cand.begin(), cand.end()), cand.end());
-	for ( unsigned T : cand ) {
-	    std::vector<unsigned> lens;
-	    for ( const Seg &s : pieces ) {
-		const unsigned k = ( s.len + T - 1 ) / T;
-		for ( unsigned q = 0; q < k; q++ )
-		    lens.push_back(s.len / k + ( q < s.len % k ? 1u : 0u ));
+	// (the assembly: ~16 instructions per segment of the longest window, once per 64 windows --
+	// per 32 where two lanes share a window, Wave::seg_correlate)
+	const unsigned asm_units = J * nb <= 32u ? 1u : 2u * ( ( J * nb + 63u ) / 64u );
+	auto cost_of = [&]( const std::vector<std::vector<unsigned>> &parts ) -> unsigned {
+	    std::vector<unsigned> lens, at;
+	    for ( size_t i = 0; i < parts.size(); i++ ) {
+		unsigned a = pieces[i].rel;
+		for ( unsigned l : parts[i] ) {
+		    lens.push_back(l);
+		    at.push_back(a);
+		    a += l;
+		}
 	    }
-	    if ( lens.size() > (size_t)SEG_MAX )
-		continue;
-	    std::sort(lens.begin(), lens.end(), [](unsigned a, unsigned b) { return a > b; });
-	    // (per pass: its groups of 16 samples, plus what a pass costs whatever its length)
-	    unsigned cost = ( lens[0] + 15 ) / 16 + 1;
-	    if ( lens.size() > 64 )
-		cost += ( lens[64] + 15 ) / 16 + 1;
-	    if ( cost < best_cost ) {
-		best_cost = cost;
-		best_T = T;
+	    if ( lens.empty() || lens.size() > (size_t)SEG_MAX )
+		return 0xFFFFFFFFu;
+	    unsigned cmax = 0;
+	    for ( unsigned a : wstart ) {
+		unsigned n = 0;
+		for ( size_t i = 0; i < lens.size(); i++ )
+		    n += ( at[i] >= a && at[i] + lens[i] <= a + B ) ? 1u : 0u;
+		cmax = std::max(cmax, n);
+	    }
+	    std::sort(lens.begin(), lens.end(), [](unsigned x, unsigned y) { return x > y; });
+	    unsigned cost = 8u * cmax * asm_units;
+	    for ( size_t p0 = 0; p0 < lens.size(); p0 += 64 ) {
+		const size_t p1 = std::min(lens.size(), p0 + 64);
+		const unsigned lmax = lens[p0], lmin = lens[p1 - 1];
+		const unsigned g = ( lmax + 15 ) / 16, st = ( g + 1 ) / 2, full = lmin / 16;
+		cost += 86u * g + 60u * st + 32u * ( g - std::min(g, full) );
+	    }
+	    return cost;
+	};
+	unsigned best_cost = 0xFFFFFFFFu;
+	std::vector<std::vector<unsigned>> best;		// the parts of every piece, in position order
+	// equal parts
+	{
+	    std::vector<unsigned> cand;
+	    for ( const Seg &s : pieces )
+		for ( unsigned k = 1; k <= 16u && s.len / k >= 16u; k++ )
+		    cand.push_back(( s.len + k - 1 ) / k);
+	    std::sort(cand.begin(), cand.end());
+	    cand.erase(std::unique(cand.begin(), cand.end()), cand.end());
+	    for ( unsigned T : cand ) {
+		std::vector<std::vector<unsigned>> parts;
+		size_t nparts = 0;
+		for ( const Seg &s : pieces ) {
+		    const unsigned k = ( s.len + T - 1 ) / T;
+		    parts.emplace_back();
+		    for ( unsigned q = 0; q < k; q++ )
+			parts.back().push_back(s.len / k + ( q < s.len % k ? 1u : 0u ));
+		    nparts += k;
+		}
+		if ( nparts > (size_t)SEG_MAX )
+		    continue;
+		const unsigned c = cost_of(parts);
+		if ( c < best_cost ) {
+		    best_cost = c;
+		    best = parts;
+		}
 	    }
 	}
-	if ( !best_T )
+	// caps
+	{
+	    unsigned lnat = 0, ltot = 0;
+	    for ( const Seg &s : pieces ) {
+		lnat = std::max(lnat, s.len);
+		ltot += s.len;
+	    }
+	    const unsigned amax = ( lnat + 15u ) & ~15u;
+	    constexpr unsigned INF = 0xFFFFu;
+	    std::vector<uint16_t> choice(pieces.size() * 65u);
+	    std::vector<unsigned> dp(65), nx(65);
+	    std::vector<std::vector<unsigned>> parts(pieces.size());
+	    // (caps in whole groups; for very long windows in coarser steps: at most 32 values)
+	    const unsigned astep = std::max(16u, ( amax / 32u + 15u ) & ~15u);
+	    for ( unsigned A0 = astep; A0 <= amax + astep - 1u; A0 += astep )
+		for ( unsigned A1 = astep; A1 <= A0; A1 += astep ) {
+		    if ( 64u * ( A0 + A1 ) < ltot )
+			continue;			// (the lanes of two passes cannot hold the span)
+		    // (a plan whose longest parts are a whole group below its caps is found under the
+		    // smaller caps: these caps cost at least their own groups and steps)
+		    if ( 86u * ( A0 / 16u + A1 / 16u ) + 60u * ( ( A0 + 16u ) / 32u + ( A1 + 16u ) / 32u ) >= best_cost )
+			continue;
+		    // dp[j]: fewest pass-1 parts with j pass-0 parts over the pieces so far
+		    std::fill(dp.begin(), dp.end(), INF);
+		    dp[0] = 0;
+		    for ( size_t i = 0; i < pieces.size(); i++ ) {
+			const unsigned L = pieces[i].len;
+			std::fill(nx.begin(), nx.end(), INF);
+			for ( unsigned j = 0; j <= 64; j++ ) {
+			    if ( dp[j] == INF )
+				continue;
+			    for ( unsigned n0 = 0; n0 <= ( L + A0 - 1 ) / A0 && j + n0 <= 64; n0++ ) {
+				const unsigned rest = L > n0 * A0 ? L - n0 * A0 : 0u;
+				const unsigned n1 = ( rest + A1 - 1 ) / A1;
+				if ( n0 + n1 == 0 || n0 + n1 > L )
+				    continue;
+				if ( dp[j] + n1 < nx[j + n0] ) {
+				    nx[j + n0] = dp[j] + n1;
+				    choice[i * 65u + j + n0] = (uint16_t)n0;
+				}
+			    }
+			}
+			dp.swap(nx);
+		    }
+		    unsigned jbest = 65;
+		    for ( unsigned j = 0; j <= 64; j++ )
+			if ( dp[j] <= 64 && ( jbest == 65 || dp[j] + j < dp[jbest] + jbest ) )
+			    jbest = j;
+		    if ( jbest == 65 )
+			continue;
+		    // walk back: n0 of every piece; its n1 follows
+		    unsigned j = jbest;
+		    for ( size_t i = pieces.size(); i-- > 0; ) {
+			const unsigned L = pieces[i].len, n0 = choice[i * 65u + j];
+			const unsigned rest = L > n0 * A0 ? L - n0 * A0 : 0u;
+			const unsigned n1 = ( rest + A1 - 1 ) / A1;
+			// pass 1's parts as long as they may be, pass 0's share the rest equally
+			unsigned t1 = n1 ? std::min(n1 * A1, L - n0) : 0u;
+			if ( n0 == 0 )
+			    t1 = L;
+			const unsigned t0 = L - t1;
+			parts[i].clear();
+			for ( unsigned q = 0; q < n0; q++ )
+			    parts[i].push_back(t0 / n0 + ( q < t0 % n0 ? 1u : 0u ));
+			for ( unsigned q = 0; q < n1; q++ )
+			    parts[i].push_back(t1 / n1 + ( q < t1 % n1 ? 1u : 0u ));
+			j -= n0;
+		    }
+		    bool sound = true;
+		    for ( const std::vector<unsigned> &pp : parts )
+			for ( unsigned l : pp )
+			    sound = sound && l >= 1u;
+		    const unsigned c = sound ? cost_of(parts) : 0xFFFFFFFFu;
+		    if ( c < best_cost ) {
+			best_cost = c;
+			best = parts;
+		    }
+		}
+	}
+	if ( best.empty() )
 	    return;
 	segs.clear();
-	for ( const Seg &s : pieces ) {
-	    const unsigned k = ( s.len + best_T - 1 ) / best_T;
-	    unsigned at = s.rel;
-	    for ( unsigned q = 0; q < k; q++ ) {
-		const unsigned l = s.len / k + ( q < s.len % k ? 1u : 0u );
+	for ( size_t i = 0; i < pieces.size(); i++ ) {
+	    unsigned at = pieces[i].rel, total = 0;
+	    for ( unsigned l : best[i] ) {
 		segs.push_back(Seg{at, l});
 		at += l;
+		total += l;
 	    }
+	    if ( total != pieces[i].len )
+		return;				// (cannot happen; leaves valid = 0)
 	}
+	if ( segs.size() > (size_t)SEG_MAX )
+	    return;
     }
     const unsigned npass = (unsigned)( ( segs.size() + 63 ) / 64 );
     // passes: longest pieces first, position order inside a pass
