@@ -302,6 +302,9 @@ typedef struct mifsk_demod_io {
 					   is not counted -- counting it through a ballot moved the
 					   register allocation of the loop kernels and cost 1-2 %
 					   (profiles/r06_history.md)                               */
+#define MIFSK_CNT_SEG_SECOND_LOOKS 25	/* shared-segment scans in which the second look (the running
+					   error bound, csrc/mifsk_wave.hip) settled a window the
+					   a-priori bound had not                                  */
 
 /* Asynchronous on `stream`: the outputs are complete when `stream` reaches the point
  * behind the call.  (A large wavefront-engine batch is run as several launches on

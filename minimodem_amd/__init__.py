@@ -40,7 +40,7 @@ COUNTER_NAMES = {0: "iterations", 1: "batches", 2: "stages", 3: "bulk_frames", 4
                  5: "cache_hits", 6: "positions", 7: "lattice_batches", 8: "cyc_total",
                  9: "cyc_scan", 10: "cyc_wait", 11: "cyc_confidence", 12: "cyc_bulk", 13: "w_stage", 14: "w_correlate",
                  15: "w_barrier", 16: "cyc_general", 17: "cyc_restart", 18: "cyc_scan1", 19: "cyc_scan2", 20: "cyc_replay_scan", 21: "cyc_scan_wait",
-                 24: "conf_fallbacks"}
+                 24: "conf_fallbacks", 25: "seg_second_looks"}
 
 
 def build(force=False):

@@ -887,7 +887,74 @@ struct Wave {
 	}
 	const uint32_t tg2 = MIFSK_WCLOCK();
 	cyc_g_asm += tg2 - tg1;
-	// the windows whose float the bound does not settle: again, in index order
+	// A second look at the windows the bound does not settle (round 6).  delta above prices the
+	// oracle's own index-order chain at its worst case, (B - 1) u sum |x|.  What that chain can
+	// really be off by is u times the sum of its partial sums' magnitudes (acc_k = (acc_{k-1} +
+	// x_k w_k)(1 + d_k), |d_k| <= u: the error is sum d_k acc_k), and inside segment s -- L_s
+	// samples, A_s = sum |x| <= sqrt(L_s E_s) -- no partial sum exceeds |P_s| + A_s, P_s the sum
+	// over the segments before it: the assembled partial sum to within this assembly's own error
+	// (u c' sum A, c' = bound_c - B, added to every |P_s|).  So
+	//     delta2 = u [ c' sum A_s + sum_s L_s ( |P_s| + A_s + u c' sum A ) ]
+	// per component -- a third of delta where the band is silent (its partial sums stay small)
+	// and on the carrying band alike.  One lane per unsettled window walks its segments once
+	// more, in order; what settles is written, the rest goes on to the index-order sum.  (A
+	// window with a NaN or an infinity settles nowhere.)
+	for ( uint32_t h = 0; h < 2u; h++ ) {
+	    const unsigned long long m = h ? redo1 : redo0;
+	    if ( !m )
+		continue;
+	    bool settled = false;
+	    if ( ( m >> lane ) & 1ull ) {
+		const uint32_t wl = 64u * h + lane;
+		const uint32_t ww = w_off + wl;
+		const uint32_t j = udiv_magic(wl, nb, cfg.nbits_magic), k = wl - j * nb;
+		const uint32_t pw = sp.p_win[ww];
+		const uint32_t first = pw & 0xFFu, cnt = ( pw >> 8 ) & 0xFFu, a_rel = pw >> 16;
+		const double cown = (double)sp.bound_c - (double)B;
+		double X[4] = { 0.0, 0.0, 0.0, 0.0 }, run[4] = { 0.0, 0.0, 0.0, 0.0 };
+		double asum = 0.0, lsum = 0.0;
+		for ( uint32_t i = 0; i < cnt; i++ ) {
+		    const uint32_t sg = first + i;
+		    const double2_a16 q0 = *reinterpret_cast<const double2_a16 *>(partD + 4u * sg);
+		    const double2_a16 q1 = *reinterpret_cast<const double2_a16 *>(partD + 4u * sg + 2u);
+		    const double L = (double)sp.seg_len[sg];
+		    const double A = sqrt(L * (double)partA[sg]) * 1.0001;	// (partA is a float sum: a little slack)
+		    const double *t = rot ? rot + 4 * ( (size_t)i * rstride + ww )
+					  : tw + 4 * (size_t)( partRel[sg] - a_rel );
+		    const double2_a16 r0 = *reinterpret_cast<const double2_a16 *>(t);
+		    const double2_a16 r1 = *reinterpret_cast<const double2_a16 *>(t + 2);
+#pragma unroll
+		    for ( int c = 0; c < 4; c++ )
+			run[c] = fma(L, fabs(X[c]) + A, run[c]);
+		    X[0] = fma(q0.x, r0.x, X[0]);  X[0] = fma(-q0.y, r0.y, X[0]);
+		    X[1] = fma(q0.x, r0.y, X[1]);  X[1] = fma(q0.y, r0.x, X[1]);
+		    X[2] = fma(q1.x, r1.x, X[2]);  X[2] = fma(-q1.y, r1.y, X[2]);
+		    X[3] = fma(q1.x, r1.y, X[3]);  X[3] = fma(q1.y, r1.x, X[3]);
+		    asum += A;
+		    lsum += L;
+		}
+		const double u = 1.1102230246251565e-16;
+		const double own = cown * asum;				// this assembly against the exact sum, in units of u
+		bool ok = true;
+#pragma unroll
+		for ( int c = 0; c < 4; c++ ) {
+		    const double d2 = 1.0001 * u * ( own + run[c] + lsum * ( u * own ) );
+		    ok = ok && (float)( X[c] - d2 ) == (float)( X[c] + d2 );
+		}
+		if ( ok ) {
+		    mags[( j - c0 ) * nb + k] = band_mag2_exact(X[0], X[1], X[2], X[3], cfg.magscalar);
+		    settled = true;
+		}
+	    }
+	    const unsigned long long still = m & ~__ballot(settled);
+	    if ( cnt_on && still != m )
+		bump(MIFSK_CNT_SEG_SECOND_LOOKS);
+	    if ( h )
+		redo1 = still;
+	    else
+		redo0 = still;
+	}
+	// ... and what is left: again, in index order
 	for ( uint32_t h = 0; h < 2u; h++ ) {
 	    const unsigned long long m = h ? redo1 : redo0;
 	    if ( !m )
