@@ -788,6 +788,11 @@ struct Wave {
 	// even ones, lane 32 + w the odd ones -- and the two halves are added at the end (another
 	// order of the same sum: two more roundings, counted in the plan's bound_c).
 	const bool split = rot != nullptr && nwin_scan <= 32u;
+	// (the sums of squares are float sums: a square below 2^-126 is rounded to a multiple of
+	// 2^-149, one below 2^-150 to zero -- audio at 1e-23 of full scale would switch the guard off.
+	// 3e-45 per sample covers what those roundings can lose; sqrt(a + b) <= sqrt(a) + sqrt(b): the
+	// bound is delta = dscale sqrt(aw) + dfloor, the multiplication an fma.)
+	const double dfloor = dscale * sqrt((double)B * 3.0e-45);
 	for ( uint32_t g0 = 0; g0 < nwin_scan; g0 += 64u ) {
 	    const uint32_t part = split ? lane >> 5 : 0u;
 	    const uint32_t w = split ? ( lane & 31u ) : g0 + lane;
@@ -871,7 +876,7 @@ struct Wave {
 		    aw += as[u];
 		}
 	    }
-	    const double delta = dscale * sqrt((double)aw);
+	    const double delta = fma(dscale, sqrt((double)aw), dfloor);
 	    const bool stable = (float)( mr - delta ) == (float)( mr + delta )
 			     && (float)( mi - delta ) == (float)( mi + delta )
 			     && (float)( sr - delta ) == (float)( sr + delta )
@@ -918,7 +923,8 @@ struct Wave {
 		    const double2_a16 q0 = *reinterpret_cast<const double2_a16 *>(partD + 4u * sg);
 		    const double2_a16 q1 = *reinterpret_cast<const double2_a16 *>(partD + 4u * sg + 2u);
 		    const double L = (double)sp.seg_len[sg];
-		    const double A = sqrt(L * (double)partA[sg]) * 1.0001;	// (partA is a float sum: a little slack)
+		    // (partA is a float sum of float squares: a little slack, and what underflow can lose)
+		    const double A = sqrt(L * ( (double)partA[sg] + L * 3.0e-45 )) * 1.0001;
 		    const double *t = rot ? rot + 4 * ( (size_t)i * rstride + ww )
 					  : tw + 4 * (size_t)( partRel[sg] - a_rel );
 		    const double2_a16 r0 = *reinterpret_cast<const double2_a16 *>(t);
