@@ -162,3 +162,27 @@ def test_windows_on_a_rounding_boundary_take_the_index_order_fallback(gpu, mode,
             break
     assert tuned >= 1, "no stream with a fallback-free baseline among the seeds"
     lib.ofsk_plan_destroy(plan)
+
+
+@pytest.mark.parametrize("mode,kw", [("rtty", {}), ("rtty", dict(sample_rate=44100))], ids=["rtty48k", "rtty44k1"])
+def test_guard_where_the_energy_sums_underflow(gpu, mode, kw):
+    """The guard's A = sum |x| comes from FLOAT sums of FLOAT squares: below 1e-19 of full scale a
+    square is a subnormal, below 1e-23 it is zero -- and a bound of zero would accept every
+    assembled sum.  What those roundings can lose is part of the bound (csrc/mifsk_wave.hip:
+    dfloor, and the second look's A_s): streams at 1e-18 ... 1e-36 of full scale go through the
+    shared segments and give the oracle's frames, confidence and amplitude bit patterns included."""
+    M, torch, ctx = gpu
+    cfg = M.rx_config(mode, **kw)
+    ocfg = O.oracle_config(mode, **kw)
+    rng = np.random.default_rng(77)
+    n_scans = 0
+    for amp in (1e-18, 1e-20, 3e-22, 1e-23, 1e-25, 1e-30, 1e-36):
+        words = rng.integers(0, 32, size=20, dtype=np.uint8)
+        x = M.synthesize(cfg, words, leading_silence=int(rng.integers(0, 40)), amplitude=1.0)
+        x = (x.astype(np.float64) * amp).astype(np.float32)
+        x = np.concatenate([x, np.zeros(4 * int(cfg.bit_nsamples), np.float32)])
+        r = _run(M, torch, ctx, cfg, x)
+        assert int(r["nframes"][0]) >= 20, (amp, int(r["nframes"][0]))
+        assert _equal_oracle(r, ocfg, x), amp
+        n_scans += int(r["counters"][0][CNT_SEG_SCANS])
+    assert n_scans > 100
