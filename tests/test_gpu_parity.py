@@ -258,8 +258,10 @@ def test_random_batch_with_noise_matches_oracle(gpu, mode, variant):
 
 
 @pytest.mark.parametrize("mode,kw", [("rtty", {}), ("rtty", dict(sample_rate=44100)), ("50", {}), ("30", {}),
-                                     ("20", {}), ("rtty", dict(sample_rate=96000))],
-                         ids=["B1056", "B970", "B960", "B1600", "B2400", "B2112"])
+                                     ("20", {}), ("rtty", dict(sample_rate=96000)),
+                                     ("75", dict(sample_rate=22050)), ("110", dict(sample_rate=96000)),
+                                     ("60", dict(sample_rate=44100)), ("100", dict(sample_rate=44100)), ("25", {})],
+                         ids=["B1056", "B970", "B960", "B1600", "B2400", "B2112", "B294", "B873", "B735", "B441", "B1920"])
 def test_long_windows_through_the_tile(gpu, mode, kw):
     """Bit windows too long for a search's span to sit in LDS are read from global memory
     through the 64-sample tile (wave engine, demod_wave_kernel<10, -1>): bit lengths that are
@@ -268,7 +270,10 @@ def test_long_windows_through_the_tile(gpu, mode, kw):
     M, torch, ctx = gpu
     cfg = M.rx_config(mode, **kw)
     ocfg = O.oracle_config(mode, **kw)
-    assert "demod_wave_kernel<10, -1>" in M.demod_plan(ctx, cfg, 8, engine="wave")["kernel"]
+    kernel = M.demod_plan(ctx, cfg, 8, engine="wave")["kernel"]
+    # (the shorter of these fit a search slab in LDS at this batch size: whichever instantiation
+    # the planner picks, the frames are the oracle's)
+    assert "demod_wave_kernel<10, -1>" in kernel or int(cfg.bit_nsamples) < 900, kernel
     rng = np.random.default_rng(77)
     five = cfg.n_data_bits == 5
     streams = []
